@@ -1,0 +1,191 @@
+/*
+ * sfm_amd.h -- C-ABI of libsfm_amd.so: the MI355X (gfx950) implementation of the
+ * SfM pipeline's data-parallel front end (pairwise descriptor matching and
+ * RANSAC two-view geometry).
+ *
+ * Plain C: opaque handles, raw pointers and sizes, int status codes, no
+ * exceptions.  Unless a parameter says "device", every pointer is host memory.
+ * Matrices are column-major (Eigen's default), so Mat3::data(), Mat4::data()
+ * and std::vector<Vec2>::data() of the reference can be passed as they are.
+ *
+ * Each entry point names the reference interface (file:line in the reference
+ * tree) whose body it replaces.
+ */
+#ifndef SFM_AMD_H
+#define SFM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define SFM_OK 0
+#define SFM_ERR_INVALID_ARG 1  /* null pointer, negative size, unknown enum     */
+#define SFM_ERR_NO_DEVICE 2    /* no HIP device / wrong architecture            */
+#define SFM_ERR_OOM 3          /* device or host allocation failed              */
+#define SFM_ERR_UNSUPPORTED 4  /* valid request this build has no kernel for    */
+#define SFM_ERR_CAPACITY 5     /* caller's output buffer too small              */
+#define SFM_ERR_HIP 6          /* a HIP runtime call failed; see sfm_last_error */
+
+/* match/match.hpp:18-46: the two similarity metrics the reference provides.
+ * (MATCHING_OPTIONS::similarityMetric holding anything else has no kernel.) */
+#define SFM_METRIC_COSINE 0
+#define SFM_METRIC_DOT 1
+
+/* match/match.hpp:10-13: matchingAlgorithm; the only value the reference has. */
+#define SFM_MATCH_TWO_SIDED 0
+
+/* solve/solve.hpp:119-124: the default RANSAC_OPTIONS::loss; Sampson is an
+ * extension with no counterpart in the reference. */
+#define SFM_LOSS_REPROJECTION 0
+#define SFM_LOSS_SAMPSON 1
+
+typedef struct sfm_ctx sfm_ctx;
+typedef struct sfm_imageset sfm_imageset;
+typedef struct sfm_match_result sfm_match_result;
+typedef struct sfm_ransac_batch sfm_ransac_batch;
+
+/* ---- context -------------------------------------------------------------
+ * One context per device per host thread.  Owns a HIP stream and a grow-only
+ * device workspace; every call below is asynchronous on that stream unless it
+ * returns data to the host.  No counterpart in the reference (it is CPU-only).
+ */
+int sfm_ctx_create(int device, sfm_ctx **ctx_out);
+void sfm_ctx_destroy(sfm_ctx *ctx);
+int sfm_ctx_synchronize(sfm_ctx *ctx);
+/* Message of the last failure on this context ("" if none). */
+const char *sfm_last_error(const sfm_ctx *ctx);
+const char *sfm_version(void);
+
+/* Tunables (all optional).  key: "cand_capacity" (candidate slots per image
+ * pair, default 32768), "pairs_per_launch" (default 2048),
+ * "hyps_per_launch".  Returns SFM_ERR_INVALID_ARG for an unknown key. */
+int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);
+
+/* Device time, in milliseconds, that the dominant kernel of the last batch
+ * call spent (sum over its launches, measured with HIP events on the
+ * context's stream), and how many launches that was.  which: 0 = matcher
+ * similarity kernel, 1 = RANSAC scoring kernel. */
+int sfm_ctx_last_kernel_ms(sfm_ctx *ctx, int which, double *ms_out, int *launches_out);
+
+/* ---- matching: one image pair ---------------------------------------------
+ * Replaces the body of
+ *   std::vector<std::tuple<int,int>> SfM::match::match(keypoints1, keypoints2, options)
+ *   (submodules/match/match.hpp:70, match.cpp:9-22 -> matchTwoSided, match.cpp:24-94)
+ * for options.similarityMetric in {cosineSimilarity, dotProduct}
+ * (match.hpp:18-46).  descA: nA x dim floats, row-major (Keypoint::descriptor,
+ * SfM.hpp:132, packed); ptsA: nA x 2 doubles (Keypoint::point, SfM.hpp:133).
+ * Writes (i, j) index pairs, ascending i, into pairs_out[2*capacity]; the
+ * count goes to *count_out.  capacity >= min(nA, nB) always suffices.
+ * algorithm other than SFM_MATCH_TWO_SIDED -> SFM_ERR_INVALID_ARG (the
+ * reference throws std::invalid_argument, match.cpp:18).  Empty inputs give
+ * count 0.  matches1_out[nA] / matches2_out[nB] (optional, may be NULL)
+ * receive the per-row / per-column best indices (match.cpp:30-31), -1 = none.
+ */
+int sfm_match_pair(sfm_ctx *ctx, int algorithm,
+                   const float *descA, const double *ptsA, int nA,
+                   const float *descB, const double *ptsB, int nB, int dim,
+                   int metric, float threshold, float max_distance_px_squared,
+                   int32_t *pairs_out, int capacity, int *count_out,
+                   int32_t *matches1_out, int32_t *matches2_out);
+
+/* ---- matching: resident image table + pair list ----------------------------
+ * The batch form of the same function, for many pairs over one image set
+ * (the reference calls match() once per consecutive frame pair,
+ * submodules/scene.cpp:60).  The image set is uploaded once and stays in HBM:
+ * desc = all descriptors back to back (sum(counts) x dim floats), pts likewise
+ * (sum(counts) x 2 doubles), counts[n_images] = keypoints per image.
+ */
+int sfm_imageset_create(sfm_ctx *ctx, int n_images, const int32_t *counts,
+                        const float *desc, const double *pts, int dim,
+                        sfm_imageset **set_out);
+/* Same, with desc/pts already in device memory of ctx's device. */
+int sfm_imageset_create_device(sfm_ctx *ctx, int n_images, const int32_t *counts,
+                               const float *desc_device, const double *pts_device, int dim,
+                               sfm_imageset **set_out);
+void sfm_imageset_destroy(sfm_imageset *set);
+/* Bytes of device memory the set holds. */
+int64_t sfm_imageset_device_bytes(const sfm_imageset *set);
+
+/* Match every (a, b) in pair_list[2*n_pairs] (image indices into the set).
+ * The result stays on the device as CSR: offsets[n_pairs+1] (int64) and
+ * pairs[2*offsets[n_pairs]] (int32 (i, j), ascending i within a pair).  The
+ * call is asynchronous; the accessors below synchronise.  A result object may
+ * be passed back in through *result_inout to reuse its buffers (pass a
+ * pointer to NULL the first time).
+ */
+int sfm_match_batch(sfm_ctx *ctx, const sfm_imageset *set,
+                    const int32_t *pair_list, int n_pairs,
+                    int metric, float threshold, float max_distance_px_squared,
+                    sfm_match_result **result_inout);
+int sfm_match_result_total(sfm_match_result *res, int64_t *total_matches_out);
+int sfm_match_result_offsets(sfm_match_result *res, int64_t *offsets_out /* n_pairs+1 */);
+int sfm_match_result_pairs(sfm_match_result *res, int32_t *pairs_out /* 2*total */);
+/* Device views (valid until the result is reused or destroyed). */
+int sfm_match_result_device(sfm_match_result *res, const int64_t **offsets_device,
+                            const int32_t **pairs_device);
+/* Number of candidate cells the exact pass evaluated / that did not fit the
+ * candidate list and were evaluated inside the similarity kernel. */
+int sfm_match_result_stats(sfm_match_result *res, int64_t *candidates_out, int64_t *overflow_out);
+void sfm_match_result_destroy(sfm_match_result *res);
+
+/* ---- RANSAC: one image pair -------------------------------------------------
+ * Replaces the body of
+ *   std::vector<int> SfM::solve::RANSAC(x, y, K, options, verbose)
+ *   (submodules/solve/solve.hpp:137, RANSAC.cpp:146-270)
+ * for options.model == eightPointAlgorithmFromSubset (eightPoint.cpp:225-372)
+ * and options.loss == the default reprojection loss (solve.hpp:119-124).
+ * x, y: n x 2 doubles, K^-1-normalised (scene.cpp:246-247); K: 3x3
+ * column-major.  samples[n_hyp][8]: the index rows to fit (the reference draws
+ * them with a time-seeded shuffle, RANSAC.cpp:170,201, so any table is a legal
+ * run); hypotheses are taken in row order, as one TBB worker would.
+ * min_n must be 8 (RANSAC_OPTIONS::minN, solve.hpp:113); other values ->
+ * SFM_ERR_UNSUPPORTED.  n < min_n -> count 0 (RANSAC.cpp:148-149).
+ * adaptive != 0 applies the maxIter update of RANSAC.cpp:245-258 while
+ * scanning the hypotheses in order.
+ * Outputs: inliers_out[capacity] ascending indices and *count_out; optional
+ * (NULL to skip): *best_hyp_out (row of samples, -1 if none), pose_out[16]
+ * (4x4 column-major [R|T] of the winner), counts_out[n_hyp], toterr_out[n_hyp],
+ * *iterations_out (hypotheses the in-order scan reached).
+ */
+int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, int n, const double *K,
+                    const int32_t *samples, int n_hyp, int min_n,
+                    double max_squared_error, double success_prob, int adaptive, int loss,
+                    int32_t *inliers_out, int capacity, int *count_out,
+                    int *best_hyp_out, double *pose_out,
+                    int32_t *counts_out, double *toterr_out, int *iterations_out);
+
+/* Fit only: pose12_out[n_hyp][12] = R row-major (9) then T (3) per sample row.
+ * Replaces the fit half of eightPointAlgorithmFromSubset (eightPoint.cpp:233-344). */
+int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n,
+                        const int32_t *samples, int n_hyp, double *pose12_out);
+
+/* ---- RANSAC: batch over many pairs ------------------------------------------
+ * CSR correspondences: pair p owns x[2*off[p] .. 2*off[p+1]) (same for y);
+ * samples[p][n_hyp][8] index into the pair's own range.  All pairs share K and
+ * the options.  Results per pair: best hypothesis, its count, its total error,
+ * its pose (12 doubles, R row-major then T), and CSR inlier lists.
+ */
+int sfm_ransac_batch_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets,
+                         const double *x, const double *y, const double *K,
+                         const int32_t *samples, int n_hyp,
+                         double max_squared_error, double success_prob, int adaptive, int loss,
+                         sfm_ransac_batch **batch_inout);
+/* Same with x, y, samples already in device memory (offsets stay on the host). */
+int sfm_ransac_batch_run_device(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets,
+                                const double *x_device, const double *y_device, const double *K,
+                                const int32_t *samples_device, int n_hyp,
+                                double max_squared_error, double success_prob, int adaptive,
+                                int loss, sfm_ransac_batch **batch_inout);
+int sfm_ransac_batch_best(sfm_ransac_batch *b, int32_t *best_hyp_out, int32_t *best_count_out,
+                          double *best_toterr_out, double *pose12_out, int32_t *iterations_out);
+int sfm_ransac_batch_inlier_offsets(sfm_ransac_batch *b, int64_t *offsets_out /* n_pairs+1 */);
+int sfm_ransac_batch_inliers(sfm_ransac_batch *b, int32_t *inliers_out);
+void sfm_ransac_batch_destroy(sfm_ransac_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_AMD_H */

@@ -1,0 +1,905 @@
+/*
+ * sfm_oracle.c -- CPU restatement of the reference's pairwise matcher and
+ * RANSAC two-view path.  TEST INFRASTRUCTURE ONLY: nothing in the shipped
+ * library links, loads or calls this file; only tests/, the smoke check and
+ * the cpu_baseline leg of bench.py do, and only as the checker / the timed
+ * CPU baseline.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures
+ * for this path, and it cannot be compiled in this environment (it needs
+ * Eigen3, OpenCV, TBB and Ceres headers, none of which are installed), so no
+ * output of the reference itself pins this file.  What pins it instead:
+ *   - the matcher uses no third-party arithmetic: every fp32 operation below
+ *     is the one the reference source spells out, in the same order
+ *     (build with -ffp-contract=off, no -ffast-math);
+ *   - the linear algebra that the reference delegates to Eigen >= 3.3
+ *     (JacobiSVD of the 8x9 system and of the 3x3 essential matrix,
+ *     colPivHouseholderQr().solve of the 3x2 triangulation system) is
+ *     replaced by the stated algorithms below; tests cross-check them against
+ *     LAPACK (numpy.linalg.svd / lstsq) to 1e-9.
+ *
+ * Reference files followed (paths relative to the reference tree):
+ *   submodules/match/match.hpp:18-46     dotProduct, cosineSimilarity
+ *   submodules/match/match.cpp:24-94     matchTwoSided
+ *   submodules/solve/eightPoint.cpp:225-372  eightPointAlgorithmFromSubset
+ *   submodules/solve/eightPoint.cpp:57-223   eightPointAlgorithm (refit)
+ *   submodules/solve/solve.hpp:85-95,119-124 reprojectionError, default loss
+ *   submodules/solve/RANSAC.cpp:14-32,146-270 safeCastToInt, RANSAC
+ *   submodules/scene.cpp:495-501         normalizePoints
+ *   submodules/SfM.hpp:8,23              REAL = double, EPSILON = 1e-6
+ *
+ * All matrices cross this API in Eigen's default layout: column-major.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SFM_EPSILON 1e-6 /* SfM.hpp:23 */
+
+/* ------------------------------------------------------------------------ */
+/* Matching                                                                  */
+/* ------------------------------------------------------------------------ */
+
+typedef float (*similarity_fn)(const float *a, const float *b, size_t n);
+
+/* match.hpp:18-27 */
+static float dot_product(const float *a, const float *b, size_t n)
+{
+    float result = 0.0f;
+    for (size_t i = 0; i < n; ++i)
+        result += a[i] * b[i];
+    return result;
+}
+
+/* match.hpp:32-46: one loop, three fp32 running sums, then
+ * dot / (sqrt(normA) * sqrt(normB)) with float sqrt. */
+static float cosine_similarity(const float *a, const float *b, size_t n)
+{
+    float dot = 0.0f;
+    float normA = 0.0f;
+    float normB = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        dot += a[i] * b[i];
+        normA += a[i] * a[i];
+        normB += b[i] * b[i];
+    }
+    return dot / (sqrtf(normA) * sqrtf(normB));
+}
+
+/* The reference reaches its metric through a std::function; keep the call
+ * indirect so the timed baseline pays the same kind of dispatch. */
+static similarity_fn volatile g_metric_table[2] = {cosine_similarity, dot_product};
+
+int sfm_oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void sfm_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* Single similarity value, for tests. metric: 0 cosine, 1 dot. */
+float sfm_oracle_similarity(const float *a, const float *b, int dim, int metric)
+{
+    return g_metric_table[metric ? 1 : 0](a, b, (size_t)dim);
+}
+
+/*
+ * match.cpp:24-94 (matchTwoSided).  descA: nA x dim row-major floats, ptsA:
+ * nA x 2 doubles (pixels); same for B.  Writes matches1[nA], matches2[nB]
+ * (either may be NULL) and up to min(nA,nB) (i, j) pairs into pairs_out.
+ * Returns the number of pairs, or -1 when the similarity matrix cannot be
+ * allocated.  The nA x nB float matrix is materialised column-major exactly
+ * as the reference does.
+ */
+int sfm_oracle_match(const float *descA, const double *ptsA, int nA,
+                     const float *descB, const double *ptsB, int nB, int dim,
+                     int metric, float threshold, float maxDistancePxSquared,
+                     int *matches1_out, int *matches2_out, int *pairs_out)
+{
+    const int lenA = nA, lenB = nB;
+    similarity_fn similarityMetric = g_metric_table[metric ? 1 : 0];
+
+    size_t cells = (size_t)(lenA > 0 ? lenA : 0) * (size_t)(lenB > 0 ? lenB : 0);
+    float *mat = (float *)malloc((cells ? cells : 1) * sizeof(float));
+    int *matches1 = (int *)malloc((size_t)(lenA > 0 ? lenA : 1) * sizeof(int));
+    int *matches2 = (int *)malloc((size_t)(lenB > 0 ? lenB : 1) * sizeof(int));
+    if (!mat || !matches1 || !matches2) {
+        free(mat);
+        free(matches1);
+        free(matches2);
+        return -1;
+    }
+
+    /* match.cpp:34-61: similarity matrix + best row per column */
+#pragma omp parallel for schedule(static)
+    for (int idx2 = 0; idx2 < lenB; idx2++) {
+        int maxIdx = -1;
+        float maxSimilarity = 0;
+        for (int idx1 = 0; idx1 < lenA; idx1++) {
+            const float *d1 = descA + (size_t)idx1 * dim;
+            const float *d2 = descB + (size_t)idx2 * dim;
+            float similarity = similarityMetric(d1, d2, (size_t)dim);
+            double dx = ptsA[2 * idx1] - ptsB[2 * idx2];
+            double dy = ptsA[2 * idx1 + 1] - ptsB[2 * idx2 + 1];
+            double squaredNorm = dx * dx + dy * dy;
+            if (similarity > threshold && squaredNorm < maxDistancePxSquared) {
+                mat[(size_t)idx2 * lenA + idx1] = similarity;
+                if (similarity > maxSimilarity) {
+                    maxSimilarity = similarity;
+                    maxIdx = idx1;
+                }
+            } else {
+                mat[(size_t)idx2 * lenA + idx1] = 0;
+            }
+        }
+        matches2[idx2] = maxIdx;
+    }
+
+    /* match.cpp:64-79: best column per row, read back from the matrix */
+#pragma omp parallel for schedule(static)
+    for (int idx1 = 0; idx1 < lenA; idx1++) {
+        int maxIdx = -1;
+        float maxSimilarity = 0;
+        for (int idx2 = 0; idx2 < lenB; idx2++) {
+            float v = mat[(size_t)idx2 * lenA + idx1];
+            if (v > maxSimilarity) {
+                maxSimilarity = v;
+                maxIdx = idx2;
+            }
+        }
+        matches1[idx1] = maxIdx;
+    }
+
+    /* match.cpp:84-91: mutual check, ascending i */
+    int count = 0;
+    for (int i = 0; i < lenA; i++) {
+        int matchIn2 = matches1[i];
+        if (matchIn2 != -1 && matches2[matchIn2] == i) {
+            if (pairs_out) {
+                pairs_out[2 * count] = i;
+                pairs_out[2 * count + 1] = matchIn2;
+            }
+            count++;
+        }
+    }
+
+    if (matches1_out && lenA > 0)
+        memcpy(matches1_out, matches1, (size_t)lenA * sizeof(int));
+    if (matches2_out && lenB > 0)
+        memcpy(matches2_out, matches2, (size_t)lenB * sizeof(int));
+    free(mat);
+    free(matches1);
+    free(matches2);
+    return count;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Small dense linear algebra standing in for Eigen                          */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * Null vector of an 8x9 matrix A (row-major a[8][9]): the unit vector q with
+ * A q = 0.  Stands in for JacobiSVD(A, ComputeFullV).matrixV().col(8)
+ * (eightPoint.cpp:254-255), which for a rank-8 A is that same vector up to
+ * sign.  Method: Householder QR of B = A^T (9x8); q is the last column of Q.
+ * Evaluation order is fixed (and mirrored by the GPU kernel): column norms
+ * and inner products are accumulated top to bottom.
+ */
+static void null_vector_8x9(const double a[8][9], double q[9])
+{
+    double B[9][8];
+    for (int r = 0; r < 9; r++)
+        for (int c = 0; c < 8; c++)
+            B[r][c] = a[c][r];
+
+    double tau[8]; /* 2 / (v.v), or 0 when the reflection is skipped */
+    for (int j = 0; j < 8; j++) {
+        double sigma = 0.0;
+        for (int r = j; r < 9; r++)
+            sigma = sigma + B[r][j] * B[r][j];
+        double nrm = sqrt(sigma);
+        if (nrm == 0.0) {
+            tau[j] = 0.0;
+            continue;
+        }
+        double alpha = (B[j][j] > 0.0) ? -nrm : nrm;
+        /* v = x - alpha e1, stored in place of x */
+        B[j][j] = B[j][j] - alpha;
+        double vv = 0.0;
+        for (int r = j; r < 9; r++)
+            vv = vv + B[r][j] * B[r][j];
+        tau[j] = 2.0 / vv;
+        for (int c = j + 1; c < 8; c++) {
+            double s = 0.0;
+            for (int r = j; r < 9; r++)
+                s = s + B[r][j] * B[r][c];
+            s = s * tau[j];
+            for (int r = j; r < 9; r++)
+                B[r][c] = B[r][c] - s * B[r][j];
+        }
+    }
+
+    for (int r = 0; r < 9; r++)
+        q[r] = 0.0;
+    q[8] = 1.0;
+    for (int j = 7; j >= 0; j--) {
+        if (tau[j] == 0.0)
+            continue;
+        double s = 0.0;
+        for (int r = j; r < 9; r++)
+            s = s + B[r][j] * q[r];
+        s = s * tau[j];
+        for (int r = j; r < 9; r++)
+            q[r] = q[r] - s * B[r][j];
+    }
+    /* Q is orthogonal, so q is unit up to rounding; renormalise like an SVD
+     * would return it. */
+    double n2 = 0.0;
+    for (int r = 0; r < 9; r++)
+        n2 = n2 + q[r] * q[r];
+    double inv = 1.0 / sqrt(n2);
+    for (int r = 0; r < 9; r++)
+        q[r] = q[r] * inv;
+}
+
+/*
+ * Right singular vector of the smallest singular value of an n x 9 matrix
+ * (row-major), n >= 9: one-sided (Hestenes) Jacobi on the columns.  Stands in
+ * for JacobiSVD(A, ComputeFullV).matrixV().col(8) in the refit overload
+ * (eightPoint.cpp:85-86).
+ */
+static void smallest_right_singular_vector_nx9(const double *a, int n, double q[9])
+{
+    double *G = (double *)malloc((size_t)n * 9 * sizeof(double));
+    double V[9][9];
+    memcpy(G, a, (size_t)n * 9 * sizeof(double));
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++)
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+
+    for (int sweep = 0; sweep < 60; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < 8; p++) {
+            for (int qc = p + 1; qc < 9; qc++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < n; i++) {
+                    double gp = G[i * 9 + p], gq = G[i * 9 + qc];
+                    alpha += gp * gp;
+                    beta += gq * gq;
+                    gamma += gp * gq;
+                }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))
+                    continue;
+                rotated = 1;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t);
+                double s = c * t;
+                for (int i = 0; i < n; i++) {
+                    double gp = G[i * 9 + p], gq = G[i * 9 + qc];
+                    G[i * 9 + p] = c * gp - s * gq;
+                    G[i * 9 + qc] = s * gp + c * gq;
+                }
+                for (int i = 0; i < 9; i++) {
+                    double vp = V[i][p], vq = V[i][qc];
+                    V[i][p] = c * vp - s * vq;
+                    V[i][qc] = s * vp + c * vq;
+                }
+            }
+        }
+        if (!rotated)
+            break;
+    }
+    int best = 0;
+    double bestn = INFINITY;
+    for (int j = 0; j < 9; j++) {
+        double nn = 0;
+        for (int i = 0; i < n; i++)
+            nn += G[i * 9 + j] * G[i * 9 + j];
+        if (nn < bestn) {
+            bestn = nn;
+            best = j;
+        }
+    }
+    for (int i = 0; i < 9; i++)
+        q[i] = V[i][best];
+    free(G);
+}
+
+/*
+ * SVD of a 3x3 matrix E (row-major e[3][3]) = U diag(S) V^T with S sorted
+ * descending.  Stands in for JacobiSVD<Mat3>(E, FullU|FullV)
+ * (eightPoint.cpp:262-265).  One-sided Jacobi on the columns of G = E;
+ * a column whose norm vanishes against S[0] is replaced by the cross product
+ * of the other two so that U stays orthogonal.
+ */
+static void svd3(const double e[3][3], double U[3][3], double S[3], double V[3][3])
+{
+    double G[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            G[i][j] = e[i][j];
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int k = 0; k < 3; k++) {
+            const int p = PQ[k][0], q = PQ[k][1];
+            double alpha = (G[0][p] * G[0][p] + G[1][p] * G[1][p]) + G[2][p] * G[2][p];
+            double beta = (G[0][q] * G[0][q] + G[1][q] * G[1][q]) + G[2][q] * G[2][q];
+            double gamma = (G[0][p] * G[0][q] + G[1][p] * G[1][q]) + G[2][p] * G[2][q];
+            if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))
+                continue;
+            rotated = 1;
+            double zeta = (beta - alpha) / (2.0 * gamma);
+            double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            double c = 1.0 / sqrt(1.0 + t * t);
+            double s = c * t;
+            for (int i = 0; i < 3; i++) {
+                double gp = G[i][p], gq = G[i][q];
+                G[i][p] = c * gp - s * gq;
+                G[i][q] = s * gp + c * gq;
+                double vp = V[i][p], vq = V[i][q];
+                V[i][p] = c * vp - s * vq;
+                V[i][q] = s * vp + c * vq;
+            }
+        }
+        if (!rotated)
+            break;
+    }
+    double nrm[3];
+    for (int j = 0; j < 3; j++)
+        nrm[j] = sqrt((G[0][j] * G[0][j] + G[1][j] * G[1][j]) + G[2][j] * G[2][j]);
+    /* stable descending order of three values */
+    int ord[3] = {0, 1, 2};
+    if (nrm[ord[1]] > nrm[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    if (nrm[ord[2]] > nrm[ord[1]]) { int t = ord[1]; ord[1] = ord[2]; ord[2] = t; }
+    if (nrm[ord[1]] > nrm[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    double Vs[3][3];
+    for (int j = 0; j < 3; j++) {
+        const int src = ord[j];
+        S[j] = nrm[src];
+        for (int i = 0; i < 3; i++) {
+            Vs[i][j] = V[i][src];
+            U[i][j] = (nrm[src] > 0.0) ? G[i][src] / nrm[src] : 0.0;
+        }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            V[i][j] = Vs[i][j];
+    /* complete U when trailing singular values vanish */
+    const double tiny = 1e-12 * S[0];
+    if (S[0] > 0.0 && S[1] <= tiny) {
+        /* rank <= 1: any unit vector orthogonal to u0 */
+        int m = 0;
+        if (fabs(U[1][0]) < fabs(U[m][0])) m = 1;
+        if (fabs(U[2][0]) < fabs(U[m][0])) m = 2;
+        double ax[3] = {0, 0, 0};
+        ax[m] = 1.0;
+        double c0 = U[1][0] * ax[2] - U[2][0] * ax[1];
+        double c1 = U[2][0] * ax[0] - U[0][0] * ax[2];
+        double c2 = U[0][0] * ax[1] - U[1][0] * ax[0];
+        double cn = sqrt((c0 * c0 + c1 * c1) + c2 * c2);
+        U[0][1] = c0 / cn; U[1][1] = c1 / cn; U[2][1] = c2 / cn;
+    }
+    if (S[0] > 0.0 && S[2] <= tiny) {
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+}
+
+/*
+ * Least-squares solution of [-a, b] * lambda = T (3x2 system), standing in
+ * for A_tri.colPivHouseholderQr().solve(T) (eightPoint.cpp:321,363) through
+ * the normal equations solved by Cramer's rule.  bb = b.b is passed in
+ * because callers hoist it per correspondence.
+ */
+static inline void triangulate_lambdas(const double a[3], const double b[3], double bb,
+                                       const double T[3], double *lambda0, double *lambda1)
+{
+    double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    double ab = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    double aT = (a[0] * T[0] + a[1] * T[1]) + a[2] * T[2];
+    double bT = (b[0] * T[0] + b[1] * T[1]) + b[2] * T[2];
+    double det = aa * bb - ab * ab;
+    *lambda0 = (ab * bT - bb * aT) / det;
+    *lambda1 = (aa * bT - ab * aT) / det;
+}
+
+/* R (row-major 3x3) times (x, y, 1): Eigen's coefficient-wise 3x3 * 3x1
+ * product, k ascending, with x1[2] == 1.0 so the last product is exact. */
+static inline void rot_apply_h(const double R[3][3], double x, double y, double out[3])
+{
+    for (int i = 0; i < 3; i++)
+        out[i] = (R[i][0] * x + R[i][1] * y) + R[i][2];
+}
+
+static inline double det3(const double M[3][3])
+{
+    return (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) -
+            M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0])) +
+           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+
+/*
+ * The fit half of eightPointAlgorithmFromSubset / eightPointAlgorithm
+ * (eightPoint.cpp:233-344 and :64-185): sample points -> (R, T).
+ * p1, p2: n x 2 doubles (K^-1-normalised).  Returns the chosen candidate
+ * index 0..3 (order (R1,T),(R1,-T),(R2,T),(R2,-T)), and optionally the four
+ * cheirality counts.
+ */
+static int fit_pose(const double *p1, const double *p2, int n, double R[3][3], double T[3],
+                    int cheirality_counts[4])
+{
+    double q[9];
+    /* eightPoint.cpp:243-251: row = [x1*x2, y1*x2, x2, x1*y2, y1*y2, y2, x1, y1, 1] */
+    if (n == 8) {
+        double A[8][9];
+        for (int i = 0; i < 8; i++) {
+            double x1 = p1[2 * i], y1 = p1[2 * i + 1];
+            double x2 = p2[2 * i], y2 = p2[2 * i + 1];
+            A[i][0] = x1 * x2; A[i][1] = y1 * x2; A[i][2] = x2;
+            A[i][3] = x1 * y2; A[i][4] = y1 * y2; A[i][5] = y2;
+            A[i][6] = x1;      A[i][7] = y1;      A[i][8] = 1.0;
+        }
+        null_vector_8x9(A, q);
+    } else {
+        double *A = (double *)malloc((size_t)n * 9 * sizeof(double));
+        for (int i = 0; i < n; i++) {
+            double x1 = p1[2 * i], y1 = p1[2 * i + 1];
+            double x2 = p2[2 * i], y2 = p2[2 * i + 1];
+            double *r = A + (size_t)i * 9;
+            r[0] = x1 * x2; r[1] = y1 * x2; r[2] = x2;
+            r[3] = x1 * y2; r[4] = y1 * y2; r[5] = y2;
+            r[6] = x1;      r[7] = y1;      r[8] = 1.0;
+        }
+        smallest_right_singular_vector_nx9(A, n, q);
+        free(A);
+    }
+
+    /* eightPoint.cpp:257-260: row-major reshape */
+    double E[3][3] = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}, {q[6], q[7], q[8]}};
+    double U[3][3], S[3], V[3][3];
+    svd3(E, U, S, V);
+
+    /* eightPoint.cpp:274-289: R1 = U Rz(+90) V^T, R2 = U Rz(-90) V^T, T = u2.
+     * U Rz(+90) has columns (u1, -u0, u2); U Rz(-90) has (-u1, u0, u2). */
+    double R1[3][3], R2[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double w = U[i][2] * V[j][2];
+            R1[i][j] = (U[i][1] * V[j][0] - U[i][0] * V[j][1]) + w;
+            R2[i][j] = (U[i][0] * V[j][1] - U[i][1] * V[j][0]) + w;
+        }
+    if (det3(R1) < 0)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R1[i][j] = -R1[i][j];
+    if (det3(R2) < 0)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R2[i][j] = -R2[i][j];
+    const double T12[3] = {U[0][2], U[1][2], U[2][2]};
+
+    /* eightPoint.cpp:296-337: cheirality vote over the sample points */
+    int maxIndex = 0, maxPoints = 0;
+    for (int c = 0; c < 4; c++) {
+        const double(*Rc)[3] = (c < 2) ? R1 : R2;
+        const double sgn = (c & 1) ? -1.0 : 1.0;
+        const double Tc[3] = {sgn * T12[0], sgn * T12[1], sgn * T12[2]};
+        int numPoints = 0;
+        for (int i = 0; i < n; i++) {
+            double a[3];
+            rot_apply_h(Rc, p1[2 * i], p1[2 * i + 1], a);
+            const double b[3] = {p2[2 * i], p2[2 * i + 1], 1.0};
+            const double bb = (b[0] * b[0] + b[1] * b[1]) + 1.0;
+            double l0, l1;
+            triangulate_lambdas(a, b, bb, Tc, &l0, &l1);
+            if (l0 > 0 && l1 > 0)
+                numPoints++;
+        }
+        if (cheirality_counts)
+            cheirality_counts[c] = numPoints;
+        if (numPoints > maxPoints) {
+            maxIndex = c;
+            maxPoints = numPoints;
+        }
+    }
+    const double(*Rb)[3] = (maxIndex < 2) ? R1 : R2;
+    const double sgn = (maxIndex & 1) ? -1.0 : 1.0;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            R[i][j] = Rb[i][j];
+        T[i] = sgn * T12[i];
+    }
+    return maxIndex;
+}
+
+/* eightPoint.cpp:349-369: depth of every correspondence in camera 1 with the
+ * fp64 -> fp32 -> fp64 round trip of lambda1 (":365 float lambda1 = lambdas[0]"),
+ * point = lambda1 * (x1, y1, 1). */
+static inline void triangulate_point(const double R[3][3], const double T[3], double x1, double y1,
+                                     double x2, double y2, double pt[3])
+{
+    double a[3];
+    rot_apply_h(R, x1, y1, a);
+    const double b[3] = {x2, y2, 1.0};
+    const double bb = (x2 * x2 + y2 * y2) + 1.0;
+    double l0, l1;
+    triangulate_lambdas(a, b, bb, T, &l0, &l1);
+    (void)l1;
+    float lambda1 = (float)l0;
+    double l = (double)lambda1;
+    pt[0] = l * x1;
+    pt[1] = l * y1;
+    pt[2] = l;
+}
+
+/* solve.hpp:85-95 with K column-major (K[r + 3*c]) and view = [R|T]. */
+static inline double reprojection_error_RT(const double *K, double ox, double oy, const double pt[3],
+                                           const double R[3][3], const double T[3])
+{
+    double q[3];
+    for (int i = 0; i < 3; i++)
+        q[i] = ((R[i][0] * pt[0] + R[i][1] * pt[1]) + R[i][2] * pt[2]) + T[i];
+    double p[3];
+    for (int i = 0; i < 3; i++)
+        p[i] = (K[i] * q[0] + K[i + 3] * q[1]) + K[i + 6] * q[2];
+    p[0] /= p[2];
+    p[1] /= p[2];
+    double obs0 = (K[0] * ox + K[3] * oy) + K[6];
+    double obs1 = (K[1] * ox + K[4] * oy) + K[7];
+    double dx = p[0] - obs0;
+    double dy = p[1] - obs1;
+    return dx * dx + dy * dy;
+}
+
+/* View matrix = identity: (I * [pt;1]).head<3>() == pt for finite pt. */
+static inline double reprojection_error_I(const double *K, double ox, double oy, const double pt[3])
+{
+    double p[3];
+    for (int i = 0; i < 3; i++)
+        p[i] = (K[i] * pt[0] + K[i + 3] * pt[1]) + K[i + 6] * pt[2];
+    p[0] /= p[2];
+    p[1] /= p[2];
+    double obs0 = (K[0] * ox + K[3] * oy) + K[6];
+    double obs1 = (K[1] * ox + K[4] * oy) + K[7];
+    double dx = p[0] - obs0;
+    double dy = p[1] - obs1;
+    return dx * dx + dy * dy;
+}
+
+/* solve.hpp:119-124: std::max(loss1, loss2) == (loss1 < loss2) ? loss2 : loss1 */
+static inline double default_loss(const double *K, double x1, double y1, double x2, double y2,
+                                  const double pt[3], const double R[3][3], const double T[3])
+{
+    double loss1 = reprojection_error_I(K, x1, y1, pt);
+    double loss2 = reprojection_error_RT(K, x2, y2, pt, R, T);
+    return (loss1 < loss2) ? loss2 : loss1;
+}
+
+/* Sampson distance in pixel^2 for E = [T]x R with K-normalised points scaled
+ * by the focal lengths of K; an extension loss with no counterpart in the
+ * reference (its algebraic residual eightPointError, solve.hpp:142-157, is
+ * unused there). */
+static inline double sampson_loss(const double *K, double x1, double y1, double x2, double y2,
+                                  const double R[3][3], const double T[3])
+{
+    double Tx[3][3] = {{0, -T[2], T[1]}, {T[2], 0, -T[0]}, {-T[1], T[0], 0}};
+    double E[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            E[i][j] = (Tx[i][0] * R[0][j] + Tx[i][1] * R[1][j]) + Tx[i][2] * R[2][j];
+    double Ex1[3], Etx2[2];
+    for (int i = 0; i < 3; i++)
+        Ex1[i] = (E[i][0] * x1 + E[i][1] * y1) + E[i][2];
+    for (int j = 0; j < 2; j++)
+        Etx2[j] = (E[0][j] * x2 + E[1][j] * y2) + E[2][j];
+    double num = (x2 * Ex1[0] + y2 * Ex1[1]) + Ex1[2];
+    double den = (Ex1[0] * Ex1[0] + Ex1[1] * Ex1[1]) + (Etx2[0] * Etx2[0] + Etx2[1] * Etx2[1]);
+    double f = 0.5 * (K[0] + K[4]);
+    return (num * num / den) * (f * f);
+}
+
+static void pose_to_colmajor16(const double R[3][3], const double T[3], double *pose16)
+{
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            pose16[r + 4 * c] = (r == c) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++)
+            pose16[r + 4 * c] = R[r][c];
+        pose16[r + 12] = T[r];
+    }
+}
+
+/*
+ * eightPointAlgorithmFromSubset (eightPoint.cpp:225-372).  calc1/calc2:
+ * n_calc x 2; all1/all2: n_all x 2.  pose16_out: 4x4 column-major;
+ * points_out: n_all x 3.  Returns the chosen candidate index, or -1 when
+ * n_calc < 8 (the reference throws std::invalid_argument, :228-231).
+ */
+int sfm_oracle_eight_point_from_subset(const double *calc1, const double *calc2, int n_calc,
+                                       const double *all1, const double *all2, int n_all,
+                                       double *pose16_out, double *points_out,
+                                       int *cheirality_counts_out)
+{
+    if (n_calc < 8)
+        return -1;
+    double R[3][3], T[3];
+    int idx = fit_pose(calc1, calc2, n_calc, R, T, cheirality_counts_out);
+    if (pose16_out)
+        pose_to_colmajor16(R, T, pose16_out);
+    if (points_out)
+        for (int i = 0; i < n_all; i++)
+            triangulate_point(R, T, all1[2 * i], all1[2 * i + 1], all2[2 * i], all2[2 * i + 1],
+                              points_out + 3 * (size_t)i);
+    return idx;
+}
+
+/* eightPointAlgorithm(points1, points2) (eightPoint.cpp:57-223): the same on
+ * one set; used for the post-RANSAC refit (scene.cpp:288). */
+int sfm_oracle_eight_point(const double *points1, const double *points2, int n,
+                           double *pose16_out, double *points_out)
+{
+    return sfm_oracle_eight_point_from_subset(points1, points2, n, points1, points2, n, pose16_out,
+                                              points_out, NULL);
+}
+
+/* The default loss for one correspondence, for tests.  pose16 column-major. */
+double sfm_oracle_loss(const double *K, const double *obs1, const double *obs2, const double *pt,
+                       const double *pose16, int loss_kind)
+{
+    double R[3][3], T[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++)
+            R[r][c] = pose16[r + 4 * c];
+        T[r] = pose16[r + 12];
+    }
+    if (loss_kind == 1)
+        return sampson_loss(K, obs1[0], obs1[1], obs2[0], obs2[1], R, T);
+    return default_loss(K, obs1[0], obs1[1], obs2[0], obs2[1], pt, R, T);
+}
+
+/* 3x3 SVD and 8x9 null vector exposed for the LAPACK cross-checks. */
+void sfm_oracle_svd3(const double *e_rowmajor, double *U_rowmajor, double *S, double *V_rowmajor)
+{
+    double e[3][3], U[3][3], V[3][3];
+    memcpy(e, e_rowmajor, sizeof e);
+    svd3(e, U, S, V);
+    memcpy(U_rowmajor, U, sizeof U);
+    memcpy(V_rowmajor, V, sizeof V);
+}
+
+void sfm_oracle_null_vector(const double *a_rowmajor, int n, double *q9)
+{
+    if (n == 8) {
+        double a[8][9];
+        memcpy(a, a_rowmajor, sizeof a);
+        null_vector_8x9(a, q9);
+    } else {
+        smallest_right_singular_vector_nx9(a_rowmajor, n, q9);
+    }
+}
+
+void sfm_oracle_triangulate(const double *a, const double *b, const double *T, double *lambdas2)
+{
+    double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    triangulate_lambdas(a, b, bb, T, &lambdas2[0], &lambdas2[1]);
+}
+
+/* RANSAC.cpp:14-32 */
+static int safe_cast_to_int(double value)
+{
+    if (isnan(value))
+        return 0;
+    if (value >= (double)INT_MAX)
+        return INT_MAX;
+    if (value <= (double)INT_MIN)
+        return INT_MIN;
+    return (int)value;
+}
+
+int sfm_oracle_adaptive_max_iter(int n_inliers, int n_total, int minN, double successProb)
+{
+    /* RANSAC.cpp:245-250; returns -1 when the cap does not apply (:248) */
+    double inlierRatio = (double)n_inliers / (double)n_total;
+    double succesProb = pow(inlierRatio, minN);
+    if (succesProb >= SFM_EPSILON)
+        return safe_cast_to_int(ceil(log(1. - successProb) / log(1 - succesProb)));
+    return -1;
+}
+
+/* Steps 2-3 of one RANSAC iteration (RANSAC.cpp:201-221) for sample row s[minN]. */
+static void score_hypothesis(const double *x, const double *y, int n, const double *K,
+                             const int *s, int minN, double maxSquaredError, int loss_kind,
+                             int *count_out, double *toterr_out, double R[3][3], double T[3])
+{
+    double cx[2 * 64], cy[2 * 64];
+    for (int k = 0; k < minN; k++) {
+        cx[2 * k] = x[2 * s[k]];
+        cx[2 * k + 1] = x[2 * s[k] + 1];
+        cy[2 * k] = y[2 * s[k]];
+        cy[2 * k + 1] = y[2 * s[k] + 1];
+    }
+    fit_pose(cx, cy, minN, R, T, NULL);
+    int count = 0;
+    double currentTotError = 0;
+    for (int k = 0; k < n; k++) {
+        double error;
+        if (loss_kind == 1) {
+            error = sampson_loss(K, x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], R, T);
+        } else {
+            double pt[3];
+            triangulate_point(R, T, x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], pt);
+            error = default_loss(K, x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], pt, R, T);
+        }
+        if (error < maxSquaredError) {
+            count++;
+            currentTotError += error;
+        }
+    }
+    *count_out = count;
+    *toterr_out = currentTotError;
+}
+
+/*
+ * solve::RANSAC (RANSAC.cpp:146-270) with an explicit sample table
+ * samples[H][minN] instead of the reference's time-seeded shuffle, evaluated
+ * in the order one TBB worker would take them (h ascending), which is one of
+ * the schedules the reference admits.  Selection: more inliers wins, equal
+ * count -> smaller total error wins (:237-238), first found keeps exact ties.
+ * adaptive != 0 applies the maxIter update of :245-258.  Every hypothesis is
+ * scored (in parallel when OpenMP is on); the serial scan afterwards decides
+ * which of them the h-ascending schedule would have reached.
+ *
+ * Outputs (any may be NULL): inliers_out[n] ascending indices, best_h,
+ * pose16 (column-major 4x4 of the best hypothesis), counts[H], toterr[H],
+ * iterations_done.  Returns the inlier count, 0 for the guard of :148-149
+ * (n < minN) and -1 for minN outside 8..64.
+ */
+int sfm_oracle_ransac(const double *x, const double *y, int n, const double *K, const int *samples,
+                      int H, int minN, double maxSquaredError, double successProb, int adaptive,
+                      int loss_kind, int *inliers_out, int *best_h_out, double *pose16_out,
+                      int *counts_out, double *toterr_out, int *iterations_done_out)
+{
+    if (best_h_out)
+        *best_h_out = -1;
+    if (iterations_done_out)
+        *iterations_done_out = 0;
+    if (minN < 8 || minN > 64)
+        return -1;
+    if (n < minN)
+        return 0;
+
+    int *counts = (int *)malloc((size_t)(H > 0 ? H : 1) * sizeof(int));
+    double *toterr = (double *)malloc((size_t)(H > 0 ? H : 1) * sizeof(double));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int h = 0; h < H; h++) {
+        double R[3][3], T[3];
+        score_hypothesis(x, y, n, K, samples + (size_t)h * minN, minN, maxSquaredError, loss_kind,
+                         &counts[h], &toterr[h], R, T);
+    }
+
+    int maxIter = H;
+    int iterationsDone = 0;
+    int bestCount = 0;
+    double bestError = INFINITY;
+    int best = -1;
+    for (int h = 0; h < H; h++) {
+        if (iterationsDone >= maxIter)
+            break;
+        iterationsDone++;
+        if (counts[h] > 0 &&
+            (counts[h] > bestCount || (counts[h] == bestCount && toterr[h] < bestError))) {
+            bestError = toterr[h];
+            bestCount = counts[h];
+            best = h;
+            if (adaptive) {
+                int newMax = sfm_oracle_adaptive_max_iter(bestCount, n, minN, successProb);
+                if (newMax >= 0 && newMax < maxIter)
+                    maxIter = newMax;
+            }
+        }
+    }
+
+    if (counts_out)
+        memcpy(counts_out, counts, (size_t)H * sizeof(int));
+    if (toterr_out)
+        memcpy(toterr_out, toterr, (size_t)H * sizeof(double));
+    if (iterations_done_out)
+        *iterations_done_out = iterationsDone;
+    if (best_h_out)
+        *best_h_out = best;
+    free(counts);
+    free(toterr);
+    if (best < 0)
+        return 0;
+
+    /* Re-run the winner to list its inliers (the reference keeps the list it
+     * built while scoring, RANSAC.cpp:218,241). */
+    double R[3][3], T[3];
+    const int *s = samples + (size_t)best * minN;
+    double cx[2 * 64], cy[2 * 64];
+    for (int k = 0; k < minN; k++) {
+        cx[2 * k] = x[2 * s[k]];
+        cx[2 * k + 1] = x[2 * s[k] + 1];
+        cy[2 * k] = y[2 * s[k]];
+        cy[2 * k + 1] = y[2 * s[k] + 1];
+    }
+    fit_pose(cx, cy, minN, R, T, NULL);
+    if (pose16_out)
+        pose_to_colmajor16(R, T, pose16_out);
+    int count = 0;
+    for (int k = 0; k < n; k++) {
+        double error;
+        if (loss_kind == 1) {
+            error = sampson_loss(K, x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], R, T);
+        } else {
+            double pt[3];
+            triangulate_point(R, T, x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], pt);
+            error = default_loss(K, x[2 * k], x[2 * k + 1], y[2 * k], y[2 * k + 1], pt, R, T);
+        }
+        if (error < maxSquaredError) {
+            if (inliers_out)
+                inliers_out[count] = k;
+            count++;
+        }
+    }
+    return count;
+}
+
+/* Per-hypothesis poses for a sample table: pose12[h] = R row-major (9) then T (3). */
+void sfm_oracle_fit_hypotheses(const double *x, const double *y, const int *samples, int H,
+                               double *pose12_out, int *candidate_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < H; h++) {
+        double cx[16], cy[16], R[3][3], T[3];
+        const int *s = samples + (size_t)h * 8;
+        for (int k = 0; k < 8; k++) {
+            cx[2 * k] = x[2 * s[k]];
+            cx[2 * k + 1] = x[2 * s[k] + 1];
+            cy[2 * k] = y[2 * s[k]];
+            cy[2 * k + 1] = y[2 * s[k] + 1];
+        }
+        int c = fit_pose(cx, cy, 8, R, T, NULL);
+        double *o = pose12_out + (size_t)h * 12;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                o[3 * i + j] = R[i][j];
+        for (int i = 0; i < 3; i++)
+            o[9 + i] = T[i];
+        if (candidate_out)
+            candidate_out[h] = c;
+    }
+}
+
+/* scene.cpp:495-501: (K^-1 [u, v, 1])_{0,1}; Kinv column-major. */
+void sfm_oracle_normalize_points(const double *Kinv, const double *pixels, int n, double *out)
+{
+    for (int i = 0; i < n; i++) {
+        double u = pixels[2 * i], v = pixels[2 * i + 1];
+        out[2 * i] = (Kinv[0] * u + Kinv[3] * v) + Kinv[6];
+        out[2 * i + 1] = (Kinv[1] * u + Kinv[4] * v) + Kinv[7];
+    }
+}

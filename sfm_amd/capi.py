@@ -1,0 +1,349 @@
+"""ctypes binding of sfm_amd/lib/libsfm_amd.so (the C-ABI declared in include/sfm_amd.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an
+exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP = range(7)
+METRIC_COSINE, METRIC_DOT = 0, 1
+MATCH_TWO_SIDED = 0
+LOSS_REPROJECTION, LOSS_SAMPSON = 0, 1
+
+_STATUS_NAMES = {1: "invalid argument", 2: "no gfx950 device", 3: "out of memory", 4: "unsupported",
+                 5: "output capacity too small", 6: "HIP runtime error"}
+
+# Every symbol include/sfm_amd.h declares.
+EXPORTED_SYMBOLS = [
+    "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_synchronize", "sfm_last_error", "sfm_version",
+    "sfm_ctx_set_option", "sfm_ctx_last_kernel_ms",
+    "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_device", "sfm_imageset_destroy",
+    "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
+    "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats",
+    "sfm_match_result_destroy",
+    "sfm_ransac_pair", "sfm_eight_point_fit", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
+    "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
+    "sfm_ransac_batch_destroy",
+]
+
+
+class SfmError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"sfm_amd error {code} ({_STATUS_NAMES.get(code, '?')}): {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C sfm_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+    P = C.POINTER
+    L.sfm_version.restype = C.c_char_p
+    L.sfm_last_error.restype = C.c_char_p
+    L.sfm_last_error.argtypes = [vp]
+    L.sfm_ctx_create.argtypes = [i32, P(vp)]
+    L.sfm_ctx_destroy.argtypes = [vp]
+    L.sfm_ctx_destroy.restype = None
+    L.sfm_ctx_synchronize.argtypes = [vp]
+    L.sfm_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.sfm_ctx_last_kernel_ms.argtypes = [vp, i32, P(f64), P(i32)]
+    L.sfm_match_pair.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, i32, P(i32), vp, vp]
+    L.sfm_imageset_create.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
+    L.sfm_imageset_create_device.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
+    L.sfm_imageset_destroy.argtypes = [vp]
+    L.sfm_imageset_destroy.restype = None
+    L.sfm_imageset_device_bytes.argtypes = [vp]
+    L.sfm_imageset_device_bytes.restype = i64
+    L.sfm_match_batch.argtypes = [vp, vp, vp, i32, i32, f32, f32, P(vp)]
+    L.sfm_match_result_total.argtypes = [vp, P(i64)]
+    L.sfm_match_result_offsets.argtypes = [vp, vp]
+    L.sfm_match_result_pairs.argtypes = [vp, vp]
+    L.sfm_match_result_device.argtypes = [vp, P(vp), P(vp)]
+    L.sfm_match_result_stats.argtypes = [vp, P(i64), P(i64)]
+    L.sfm_match_result_destroy.argtypes = [vp]
+    L.sfm_match_result_destroy.restype = None
+    L.sfm_ransac_pair.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, f64, f64, i32, i32, vp, i32, P(i32),
+                                  P(i32), vp, vp, vp, P(i32)]
+    L.sfm_eight_point_fit.argtypes = [vp, vp, vp, i32, vp, i32, vp]
+    L.sfm_ransac_batch_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
+    L.sfm_ransac_batch_run_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
+    L.sfm_ransac_batch_best.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sfm_ransac_batch_inlier_offsets.argtypes = [vp, vp]
+    L.sfm_ransac_batch_inliers.argtypes = [vp, vp]
+    L.sfm_ransac_batch_destroy.argtypes = [vp]
+    L.sfm_ransac_batch_destroy.restype = None
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One device context (HIP stream + workspace)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        rc = lib().sfm_ctx_create(int(device), C.byref(self._h))
+        if rc != OK:
+            raise SfmError(rc, f"sfm_ctx_create(device={device})")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().sfm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def check(self, rc: int):
+        if rc != OK:
+            raise SfmError(rc, lib().sfm_last_error(self._h).decode())
+
+    def synchronize(self):
+        self.check(lib().sfm_ctx_synchronize(self._h))
+
+    def set_option(self, key: str, value: int):
+        self.check(lib().sfm_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def last_kernel_ms(self, which: int = 0):
+        ms, n = C.c_double(0), C.c_int(0)
+        self.check(lib().sfm_ctx_last_kernel_ms(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- matching -------------------------------------------------------------------------
+    def match_pair(self, descA, ptsA, descB, ptsB, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE,
+                   algorithm=MATCH_TWO_SIDED, return_best=False):
+        descA = np.ascontiguousarray(descA, np.float32)
+        descB = np.ascontiguousarray(descB, np.float32)
+        ptsA = np.ascontiguousarray(ptsA, np.float64).reshape(-1, 2)
+        ptsB = np.ascontiguousarray(ptsB, np.float64).reshape(-1, 2)
+        nA, nB = len(ptsA), len(ptsB)
+        dim = descA.shape[1] if descA.ndim == 2 and descA.shape[0] else (descB.shape[1] if descB.ndim == 2 else 128)
+        cap = max(min(nA, nB), 1)
+        pairs = np.zeros((cap, 2), np.int32)
+        m1 = np.full(max(nA, 1), -1, np.int32)
+        m2 = np.full(max(nB, 1), -1, np.int32)
+        cnt = C.c_int(0)
+        self.check(lib().sfm_match_pair(self._h, algorithm, _ptr(descA), _ptr(ptsA), nA, _ptr(descB), _ptr(ptsB),
+                                        nB, dim, metric, threshold, max_dist_sq, _ptr(pairs), cap,
+                                        C.byref(cnt), _ptr(m1), _ptr(m2)))
+        out = pairs[:cnt.value].copy()
+        if return_best:
+            return out, m1[:nA].copy(), m2[:nB].copy()
+        return out
+
+    def imageset(self, counts, desc, pts, dim=None):
+        return ImageSet(self, counts, desc, pts, dim)
+
+    # ---- RANSAC ---------------------------------------------------------------------------
+    def ransac_pair(self, x, y, K, samples, max_sq_err=10.0, success_prob=0.99, adaptive=True, min_n=8,
+                    loss=LOSS_REPROJECTION):
+        x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
+        y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
+        if len(x) != len(y):  # RANSAC.cpp:148
+            return dict(inliers=np.zeros(0, np.int32), best_h=-1, pose=np.eye(4), counts=None, toterr=None,
+                        iterations=0)
+        Kc = np.asfortranarray(K, np.float64).reshape(-1, order="F").copy()
+        samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8 if min_n == 8 else min_n)
+        H, n = samples.shape[0], len(x)
+        inl = np.zeros(max(n, 1), np.int32)
+        pose = np.eye(4).reshape(-1, order="F").copy()
+        counts = np.zeros(max(H, 1), np.int32)
+        toterr = np.zeros(max(H, 1), np.float64)
+        cnt, best, iters = C.c_int(0), C.c_int(-1), C.c_int(0)
+        self.check(lib().sfm_ransac_pair(self._h, _ptr(x), _ptr(y), n, _ptr(Kc), _ptr(samples), H, min_n,
+                                         max_sq_err, success_prob, int(bool(adaptive)), loss, _ptr(inl), max(n, 1),
+                                         C.byref(cnt), C.byref(best), _ptr(pose), _ptr(counts), _ptr(toterr),
+                                         C.byref(iters)))
+        return dict(inliers=inl[:cnt.value].copy(), best_h=best.value, pose=pose.reshape(4, 4, order="F").copy(),
+                    counts=counts[:H].copy(), toterr=toterr[:H].copy(), iterations=iters.value)
+
+    def eight_point_fit(self, x, y, samples):
+        x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
+        y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
+        samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8)
+        H = samples.shape[0]
+        pose12 = np.zeros((max(H, 1), 12))
+        self.check(lib().sfm_eight_point_fit(self._h, _ptr(x), _ptr(y), len(x), _ptr(samples), H, _ptr(pose12)))
+        return pose12[:H]
+
+    def ransac_batch(self, corr_offsets, x, y, K, samples, n_hyp, max_sq_err=10.0, success_prob=0.99,
+                     adaptive=False, loss=LOSS_REPROJECTION, batch=None, device_ptrs=None):
+        """x, y: concatenated correspondences (host arrays), or pass device_ptrs=(x_ptr, y_ptr, samples_ptr)."""
+        off = np.ascontiguousarray(corr_offsets, np.int64)
+        P = len(off) - 1
+        Kc = np.asfortranarray(K, np.float64).reshape(-1, order="F").copy()
+        b = batch if batch is not None else RansacBatch(self)
+        if device_ptrs is not None:
+            xp, yp, sp = device_ptrs
+            self.check(lib().sfm_ransac_batch_run_device(self._h, P, _ptr(off), C.c_void_p(xp), C.c_void_p(yp),
+                                                         _ptr(Kc), C.c_void_p(sp), n_hyp, max_sq_err, success_prob,
+                                                         int(bool(adaptive)), loss, C.byref(b._h)))
+        else:
+            x = np.ascontiguousarray(x, np.float64)
+            y = np.ascontiguousarray(y, np.float64)
+            samples = np.ascontiguousarray(samples, np.int32)
+            self.check(lib().sfm_ransac_batch_run(self._h, P, _ptr(off), _ptr(x), _ptr(y), _ptr(Kc), _ptr(samples),
+                                                  n_hyp, max_sq_err, success_prob, int(bool(adaptive)), loss,
+                                                  C.byref(b._h)))
+        b.n_pairs = P
+        return b
+
+
+class ImageSet:
+    """Descriptor/point table resident in HBM (sfm_imageset_*)."""
+
+    def __init__(self, ctx: Context, counts, desc, pts, dim=None):
+        self.ctx = ctx
+        counts = np.ascontiguousarray(counts, np.int32)
+        self._h = C.c_void_p()
+        self.n_images = len(counts)
+        if isinstance(desc, np.ndarray):
+            desc = np.ascontiguousarray(desc, np.float32)
+            pts = np.ascontiguousarray(pts, np.float64)
+            if dim is None:
+                dim = desc.shape[-1]
+            ctx.check(lib().sfm_imageset_create(ctx._h, len(counts), _ptr(counts), _ptr(desc), _ptr(pts), dim,
+                                                C.byref(self._h)))
+        else:  # (device pointer ints); the caller keeps the memory alive
+            ctx.check(lib().sfm_imageset_create_device(ctx._h, len(counts), _ptr(counts), C.c_void_p(int(desc)),
+                                                       C.c_void_p(int(pts)), dim, C.byref(self._h)))
+        self.counts = counts
+
+    def device_bytes(self) -> int:
+        return int(lib().sfm_imageset_device_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            lib().sfm_imageset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match(self, pair_list, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE, result=None):
+        pl = np.ascontiguousarray(pair_list, np.int32).reshape(-1, 2)
+        res = result if result is not None else MatchResult(self.ctx)
+        self.ctx.check(lib().sfm_match_batch(self.ctx._h, self._h, _ptr(pl), len(pl), metric, threshold,
+                                             max_dist_sq, C.byref(res._h)))
+        res.n_pairs = len(pl)
+        return res
+
+
+class MatchResult:
+    """CSR match lists of a batch, resident on the device until fetched."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self.n_pairs = 0
+
+    def total(self) -> int:
+        t = C.c_int64(0)
+        self.ctx.check(lib().sfm_match_result_total(self._h, C.byref(t)))
+        return t.value
+
+    def offsets(self) -> np.ndarray:
+        off = np.zeros(self.n_pairs + 1, np.int64)
+        self.ctx.check(lib().sfm_match_result_offsets(self._h, _ptr(off)))
+        return off
+
+    def pairs(self) -> np.ndarray:
+        out = np.zeros((max(self.total(), 1), 2), np.int32)
+        self.ctx.check(lib().sfm_match_result_pairs(self._h, _ptr(out)))
+        return out[:self.total()]
+
+    def device_ptrs(self):
+        o, p = C.c_void_p(), C.c_void_p()
+        self.ctx.check(lib().sfm_match_result_device(self._h, C.byref(o), C.byref(p)))
+        return o.value, p.value
+
+    def stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.ctx.check(lib().sfm_match_result_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().sfm_match_result_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RansacBatch:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self.n_pairs = 0
+
+    def best(self):
+        P = max(self.n_pairs, 1)
+        bh = np.zeros(P, np.int32)
+        bc = np.zeros(P, np.int32)
+        be = np.zeros(P, np.float64)
+        pose = np.zeros((P, 12), np.float64)
+        it = np.zeros(P, np.int32)
+        self.ctx.check(lib().sfm_ransac_batch_best(self._h, _ptr(bh), _ptr(bc), _ptr(be), _ptr(pose), _ptr(it)))
+        n = self.n_pairs
+        return dict(best_h=bh[:n], count=bc[:n], toterr=be[:n], pose12=pose[:n], iterations=it[:n])
+
+    def inlier_offsets(self):
+        off = np.zeros(self.n_pairs + 1, np.int64)
+        self.ctx.check(lib().sfm_ransac_batch_inlier_offsets(self._h, _ptr(off)))
+        return off
+
+    def inliers(self):
+        off = self.inlier_offsets()
+        out = np.zeros(max(int(off[-1]), 1), np.int32)
+        self.ctx.check(lib().sfm_ransac_batch_inliers(self._h, _ptr(out)))
+        return off, out[:int(off[-1])]
+
+    def close(self):
+        if self._h:
+            lib().sfm_ransac_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,110 @@
+// Shared host-side plumbing of libsfm_amd.so: context, error reporting, device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sfm_amd.h"
+
+struct sfm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // tunables
+    int64_t cand_capacity = 32768;   // candidate slots per image pair
+    int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
+    int64_t hyps_per_launch = 0;     // 0 = all hypotheses of a RANSAC call in one launch
+    // timing of the dominant kernels (HIP events on `stream`)
+    struct Span { hipEvent_t a, b; };
+    std::vector<Span> span_pool[2]; // events are created once and reused
+    size_t span_used[2] = {0, 0};
+    int n_cus = 256;
+};
+
+#define SFM_FAIL(ctx, code, ...)                                   \
+    do {                                                           \
+        char _buf[512];                                            \
+        snprintf(_buf, sizeof _buf, __VA_ARGS__);                  \
+        if (ctx) (ctx)->last_error = _buf;                         \
+        return (code);                                             \
+    } while (0)
+
+#define SFM_HIP(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            int _code = (_e == hipErrorOutOfMemory) ? SFM_ERR_OOM : SFM_ERR_HIP;        \
+            SFM_FAIL(ctx, _code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                               \
+        }                                                                               \
+    } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Pinned host staging buffer (grow-only).
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Event-pair timing of one kernel launch on ctx->stream.
+hipError_t sfm_span_begin(sfm_ctx *ctx, int which);
+hipError_t sfm_span_end(sfm_ctx *ctx, int which);
+void sfm_span_reset(sfm_ctx *ctx, int which);
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

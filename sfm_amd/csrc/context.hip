@@ -1,0 +1,109 @@
+// Context lifetime, options, error text and kernel timing spans.
+#include "common.h"
+
+extern "C" const char *sfm_version(void) { return "sfm_amd 0.1 (gfx950)"; }
+
+extern "C" int sfm_ctx_create(int device, sfm_ctx **ctx_out)
+{
+    if (!ctx_out) return SFM_ERR_INVALID_ARG;
+    *ctx_out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SFM_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return SFM_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return SFM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SFM_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "sfm_amd: device %d is %s; this library carries gfx950 code only\n", device,
+                prop.gcnArchName);
+        return SFM_ERR_NO_DEVICE;
+    }
+    sfm_ctx *c = new (std::nothrow) sfm_ctx();
+    if (!c) return SFM_ERR_OOM;
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SFM_ERR_HIP;
+    }
+    *ctx_out = c;
+    return SFM_OK;
+}
+
+extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    for (int w = 0; w < 2; w++)
+        for (auto &s : ctx->span_pool[w]) {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+    delete ctx;
+}
+
+extern "C" int sfm_ctx_synchronize(sfm_ctx *ctx)
+{
+    if (!ctx) return SFM_ERR_INVALID_ARG;
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+extern "C" const char *sfm_last_error(const sfm_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return SFM_ERR_INVALID_ARG;
+    if (!strcmp(key, "cand_capacity")) {
+        if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "cand_capacity must be >= 0");
+        ctx->cand_capacity = value;
+    } else if (!strcmp(key, "pairs_per_launch")) {
+        if (value < 1) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "pairs_per_launch must be >= 1");
+        ctx->pairs_per_launch = value;
+    } else if (!strcmp(key, "hyps_per_launch")) {
+        if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "hyps_per_launch must be >= 0");
+        ctx->hyps_per_launch = value;
+    } else {
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "unknown option '%s'", key);
+    }
+    return SFM_OK;
+}
+
+void sfm_span_reset(sfm_ctx *ctx, int which) { ctx->span_used[which] = 0; }
+
+hipError_t sfm_span_begin(sfm_ctx *ctx, int which)
+{
+    if (ctx->span_used[which] == ctx->span_pool[which].size()) {
+        sfm_ctx::Span s;
+        hipError_t r = hipEventCreate(&s.a);
+        if (r != hipSuccess) return r;
+        r = hipEventCreate(&s.b);
+        if (r != hipSuccess) return r;
+        ctx->span_pool[which].push_back(s);
+    }
+    return hipEventRecord(ctx->span_pool[which][ctx->span_used[which]].a, ctx->stream);
+}
+
+hipError_t sfm_span_end(sfm_ctx *ctx, int which)
+{
+    return hipEventRecord(ctx->span_pool[which][ctx->span_used[which]++].b, ctx->stream);
+}
+
+extern "C" int sfm_ctx_last_kernel_ms(sfm_ctx *ctx, int which, double *ms_out, int *launches_out)
+{
+    if (!ctx || which < 0 || which > 1) return SFM_ERR_INVALID_ARG;
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    for (size_t k = 0; k < ctx->span_used[which]; k++) {
+        float ms = 0;
+        SFM_HIP(ctx, hipEventElapsedTime(&ms, ctx->span_pool[which][k].a, ctx->span_pool[which][k].b));
+        total += ms;
+    }
+    if (ms_out) *ms_out = total;
+    if (launches_out) *launches_out = (int)ctx->span_used[which];
+    return SFM_OK;
+}

@@ -1,0 +1,876 @@
+// Pairwise descriptor matching on gfx950.
+//
+// What is computed is matchTwoSided of the reference (submodules/match/match.cpp:24-94):
+// for every cell (i, j) of the nA x nB grid, sim = metric(descA_i, descB_j) in fp32
+// (match.hpp:18-46); the cell passes if sim > threshold and the squared pixel distance
+// (fp64) is below maxDistancePxSquared; matches2[j] / matches1[i] are the lowest-index
+// arg-max over passing cells with sim > 0; the output is every (i, matches1[i]) whose
+// choice is mutual.
+//
+// How: the N x M similarity matrix is never stored.
+//   1. ingest (once per image set): per descriptor the fp32 squared norm in the reference's
+//      summation order and its sqrtf; an fp16 copy of the descriptor divided by that norm.
+//   2. match_sim_kernel: fp16 MFMA (v_mfma_f32_32x32x16_f16) over LDS-staged tiles gives an
+//      approximation of the cosine of every cell, good to 1.0e-3 absolute.  A cell whose
+//      approximation clears max(threshold, 0) - 1.5e-3 is a *candidate*; its (i, j) goes to
+//      the pair's candidate list.  Nothing else leaves the kernel.
+//   3. match_cand_kernel: every candidate is re-evaluated exactly as the reference does it
+//      (128 sequential fp32 multiply-adds without contraction, IEEE sqrt/divide, fp64 pixel
+//      gate) and folded into per-row / per-column 64-bit keys (sim bits : ~index) with
+//      atomicMax, which is the reference's arg-max including its lowest-index tie rule.
+//   4. match_mutual_kernel: mutual check and ordered compaction into CSR.
+// Since every cell that the reference could accept is a candidate, and candidates are
+// scored with the reference's own arithmetic, the result is bit-identical to the
+// reference's for any finite input, not only for integer-valued SIFT descriptors.
+#include "common.h"
+
+// Every fp32/fp64 operation of the exact pass must be the one written: no fused multiply-adds.
+#pragma clang fp contract(off)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+#define KDIM 128         // padded descriptor length of the fp16 table
+#define ROW_PAD 512      // every image's fp16 rows are padded to a multiple of this
+#define BN 128           // B descriptors staged in LDS per step
+#define SIM_MARGIN 1.5e-3f
+
+// flags per image
+#define IMG_WILD_COS 1 // a descriptor norm outside [1e-12, 1e12] (and not 0/inf/nan)
+#define IMG_WILD_DOT 2 // a descriptor norm that is 0, non-finite or outside that range
+
+struct PairRec {
+    int32_t nA, nB;
+    int64_t rowA32, rowB32; // first row in desc32 / norms / pts
+    int64_t rowA16, rowB16; // first row in desc16
+    int64_t bestRow, bestCol; // first slot in the best[] array of the chunk
+    float thr_m;            // candidate bound on the approximate cosine
+    int32_t chunkLocal;     // index inside the chunk
+};
+
+struct MatchArgs {
+    const _Float16 *desc16;
+    const float *desc32;
+    const float *norms;
+    const double2 *pts;
+    const PairRec *pairs; // chunk base
+    const int2 *work;     // (pair in chunk, row block), -1 = no work
+    uint2 *cand;          // [pairs in chunk][candCap]
+    int *candCount;       // [pairs in chunk]
+    u64 *best;            // row keys and column keys of the chunk
+    u64 *stats;           // [0] candidates scored from lists, [1] overflow cells
+    int candCap;
+    int dim;
+    int metric;
+    float threshold;
+    float maxDistSq;
+};
+
+// ---------------------------------------------------------------------------------------
+// ingest
+// ---------------------------------------------------------------------------------------
+struct ImageRec {
+    int32_t n;
+    int32_t pad;
+    int64_t row32;
+    int64_t row16;
+};
+
+// One thread per descriptor: normA += a[i]*a[i] in index order, no contraction
+// (match.hpp:38-43), then sqrtf.
+__global__ void ingest_norm_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+                                   int dim, float *__restrict__ norms, int *__restrict__ imageFlags)
+{
+    const ImageRec im = images[blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= im.n) return;
+    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
+    float normA = 0.0f;
+    for (int k = 0; k < dim; k++) normA = __fadd_rn(normA, __fmul_rn(a[k], a[k]));
+    const float s = __fsqrt_rn(normA);
+    norms[im.row32 + r] = s;
+    const bool inRange = (s >= 1e-12f) && (s <= 1e12f);
+    int f = 0;
+    if (!inRange) {
+        f |= IMG_WILD_DOT;
+        if (s != 0.0f && s == s && s != INFINITY) f |= IMG_WILD_COS;
+    }
+    if (f) atomicOr(&imageFlags[blockIdx.y], f);
+}
+
+// One thread per 8 elements of the fp16 table: a / norm rounded to fp16; rows whose norm is
+// outside the safe range, and the padding beyond dim, are zero.
+__global__ void ingest_f16_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+                                  const float *__restrict__ norms, int dim, _Float16 *__restrict__ desc16)
+{
+    const ImageRec im = images[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t >> 4, k0 = (t & 15) * 8;
+    if (r >= im.n) return;
+    const float s = norms[im.row32 + r];
+    const bool ok = (s >= 1e-12f) && (s <= 1e12f);
+    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
+    half8 out;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = k0 + e;
+        float v = 0.0f;
+        if (ok && k < dim) v = __fdiv_rn(a[k], s);
+        out[e] = (_Float16)v;
+    }
+    *reinterpret_cast<half8 *>(desc16 + (size_t)(im.row16 + r) * KDIM + k0) = out;
+}
+
+// ---------------------------------------------------------------------------------------
+// exact evaluation of one cell, as the reference computes it
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void fold_cell(const MatchArgs &g, const PairRec &pr, int i, int j)
+{
+    const float *a = g.desc32 + (size_t)(pr.rowA32 + i) * g.dim;
+    const float *b = g.desc32 + (size_t)(pr.rowB32 + j) * g.dim;
+    float dot = 0.0f;
+    if ((g.dim & 3) == 0) {
+        for (int k = 0; k < g.dim; k += 4) {
+            const float4 av = *reinterpret_cast<const float4 *>(a + k);
+            const float4 bv = *reinterpret_cast<const float4 *>(b + k);
+            dot = __fadd_rn(dot, __fmul_rn(av.x, bv.x));
+            dot = __fadd_rn(dot, __fmul_rn(av.y, bv.y));
+            dot = __fadd_rn(dot, __fmul_rn(av.z, bv.z));
+            dot = __fadd_rn(dot, __fmul_rn(av.w, bv.w));
+        }
+    } else {
+        for (int k = 0; k < g.dim; k++) dot = __fadd_rn(dot, __fmul_rn(a[k], b[k]));
+    }
+    float sim = dot; // match.hpp:18-27
+    if (g.metric == SFM_METRIC_COSINE) // match.hpp:45
+        sim = __fdiv_rn(dot, __fmul_rn(g.norms[pr.rowA32 + i], g.norms[pr.rowB32 + j]));
+    if (!(sim > g.threshold)) return; // match.cpp:45
+    const double2 pa = g.pts[pr.rowA32 + i], pb = g.pts[pr.rowB32 + j];
+    const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
+    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+    if (!(d2 < (double)g.maxDistSq)) return;
+    if (!(sim > 0.0f)) return; // match.cpp:38,49 / :68,72: must beat maxSimilarity = 0
+    // max sim first, then lowest index: the strict '>' scans of match.cpp:49 and :72.
+    const u64 bits = (u64)__float_as_uint(sim) << 32;
+    atomicMax(&g.best[pr.bestRow + i], bits | (u64)(0xFFFFFFFFu - (unsigned)j));
+    atomicMax(&g.best[pr.bestCol + j], bits | (u64)(0xFFFFFFFFu - (unsigned)i));
+}
+
+// Out-of-line so that the similarity kernel's register budget is set by its main loop.
+__device__ __noinline__ void fold_cell_overflow(const MatchArgs *g, int pairInChunk, int i, int j)
+{
+    const PairRec pr = g->pairs[pairInChunk];
+    fold_cell(*g, pr, i, j);
+}
+
+__device__ __forceinline__ void emit_candidate(const MatchArgs &g, const PairRec &pr, int i, int j)
+{
+    const int slot = atomicAdd(&g.candCount[pr.chunkLocal], 1);
+    if (slot < g.candCap) {
+        g.cand[(size_t)pr.chunkLocal * g.candCap + slot] = make_uint2((unsigned)i, (unsigned)j);
+    } else {
+        fold_cell_overflow(&g, pr.chunkLocal, i, j);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// similarity kernel
+// ---------------------------------------------------------------------------------------
+// Block = WAVES waves.  Wave w keeps RT*32 rows of image A as MFMA A-operand fragments in
+// registers for the whole block; image B streams through LDS, BN descriptors per step,
+// double buffered, one barrier per step.  LDS rows are 256 B (128 fp16); 16-byte chunk c of
+// row r is stored at chunk c ^ (r & 15), which makes the ds_read_b128 fragment reads
+// (32 rows, same logical chunk) conflict-free.
+//
+// MFMA operand map (32x32x16, f16): lane l, r = l & 31, h = l >> 5 holds A[row r][k = 8h..8h+7]
+// and B[k = 8h..8h+7][col r]; result register q of lane l is C[(q&3) + 8*(q>>2) + 4*h][r].
+template <int RT, int WAVES, bool DOT>
+__global__ __launch_bounds__(WAVES * 64) void match_sim_kernel(const MatchArgs g)
+{
+    constexpr int NT = WAVES * 64;
+    constexpr int PIECES = BN * 16 / NT; // 16-byte pieces of one B step per thread
+    static_assert(BN * 16 % NT == 0, "staging must divide evenly");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BN * 256];
+
+    const int2 w = g.work[blockIdx.x];
+    if (w.x < 0) return;
+    const PairRec pr = g.pairs[w.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rowBase = w.y * (WAVES * RT * 32) + wave * (RT * 32);
+
+    const _Float16 *A16 = g.desc16 + (size_t)(pr.rowA16 + rowBase) * KDIM;
+    const unsigned char *B16 = reinterpret_cast<const unsigned char *>(g.desc16 + (size_t)pr.rowB16 * KDIM);
+
+    half8 a[RT][8];
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            a[t][s] = *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
+
+    const int nChunks = (pr.nB + BN - 1) / BN;
+    // the bound is the same for the whole block: keep it (and the branch on it) scalar
+    const int thrBits = __builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m));
+    const float thr_m = __int_as_float(thrBits);
+    const bool posThr = thr_m >= 0.0f;
+
+    uint4 stage[PIECES];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < PIECES; u++) {
+            const int q = tid + NT * u;
+            stage[u] = *reinterpret_cast<const uint4 *>(B16 + ((size_t)c * BN + (q >> 4)) * 256 + (q & 15) * 16);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PIECES; u++) {
+            const int q = tid + NT * u;
+            const int row = q >> 4, ch = q & 15;
+            *reinterpret_cast<uint4 *>(&lds[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[u];
+        }
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    for (int c = 0; c < nChunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nChunks) stage_load(c + 1);
+
+#pragma unroll
+        for (int sub = 0; sub < BN / 32; sub++) {
+            float16v acc[RT];
+#pragma unroll
+            for (int t = 0; t < RT; t++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[t][q] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const half8 b = *reinterpret_cast<const half8 *>(
+                    &lds[buf][(sub * 32 + r) * 256 + (((2 * s + h) ^ (r & 15)) << 4)]);
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][s], b, acc[t], 0, 0, 0);
+            }
+
+            bool hit = false;
+            if (DOT) {
+                hit = true;
+            } else if (posThr) {
+                // non-negative bound: float order == signed-int order of the bit patterns
+                int m = (int)0x80000000;
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) m = max(m, __float_as_int(acc[t][q]));
+                hit = m > thrBits;
+            } else {
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++) hit |= acc[t][q] > thr_m;
+            }
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+                // rare path: one bit per accumulator register that is a candidate
+                const int j = c * BN + sub * 32 + r;
+                u64 mask = 0;
+                if (DOT) {
+                    // dot = approx * sA * sB within 1e-3 * sA * sB
+                    const float thrp = fmaxf(g.threshold, 0.0f);
+                    const float invB = (j < pr.nB) ? thrp / g.norms[pr.rowB32 + j] : 0.0f;
+#pragma unroll
+                    for (int t = 0; t < RT; t++)
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            const int i = rowBase + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            const float invA = (i < pr.nA) ? 1.0f / g.norms[pr.rowA32 + i] : 0.0f;
+                            const bool cnd = (acc[t][q] - invA * invB) > -SIM_MARGIN || !(thr_m > -INFINITY);
+                            mask |= (u64)cnd << (t * 16 + q);
+                        }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RT; t++)
+#pragma unroll
+                        for (int q = 0; q < 16; q++) mask |= (u64)(acc[t][q] > thr_m) << (t * 16 + q);
+                }
+                if (j >= pr.nB) mask = 0;
+                while (mask) {
+                    const int bit = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int q = bit & 15;
+                    const int i = rowBase + (bit >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (i < pr.nA) emit_candidate(g, pr, i, j);
+                }
+            }
+        }
+
+        if (c + 1 < nChunks) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// exact pass over the candidate lists
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
+{
+    const int p = blockIdx.y;
+    const PairRec pr = g.pairs[p];
+    int n = g.candCount[p];
+    if (n > g.candCap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.stats[1], (u64)(n - g.candCap));
+        n = g.candCap;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.stats[0], (u64)n);
+    const uint2 *list = g.cand + (size_t)p * g.candCap;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint2 c = list[k];
+        fold_cell(g, pr, (int)c.x, (int)c.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mutual check + ordered compaction (match.cpp:84-91)
+// ---------------------------------------------------------------------------------------
+// One block per pair.  WRITE = false counts, WRITE = true writes (i, j) at offsets[p].
+template <bool WRITE>
+__global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__restrict__ pairs,
+                                                           const u64 *__restrict__ best,
+                                                           int *__restrict__ counts,
+                                                           const int64_t *__restrict__ offsets,
+                                                           int2 *__restrict__ out,
+                                                           int32_t *__restrict__ m1out,
+                                                           int32_t *__restrict__ m2out)
+{
+    __shared__ int waveCnt[4];
+    const int p = blockIdx.x;
+    const PairRec pr = pairs[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 *rowKey = best + pr.bestRow;
+    const u64 *colKey = best + pr.bestCol;
+    int2 *dst = WRITE ? out + offsets[p] : nullptr;
+    int running = 0;
+    for (int base = 0; base < pr.nA; base += 256) {
+        const int i = base + tid;
+        bool ok = false;
+        int j = -1;
+        if (i < pr.nA) {
+            const u64 kr = rowKey[i];
+            if (kr != 0) {
+                j = (int)(0xFFFFFFFFu - (unsigned)kr);
+                const u64 kc = colKey[j];
+                ok = kc != 0 && (int)(0xFFFFFFFFu - (unsigned)kc) == i;
+            }
+            if (WRITE && m1out) m1out[i] = j;
+        }
+        const u64 mask = __builtin_amdgcn_ballot_w64(ok);
+        const int prefix = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
+        __syncthreads();
+        int off = running, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < wave) off += waveCnt[k];
+            tot += waveCnt[k];
+        }
+        if (WRITE && ok) dst[off + prefix] = make_int2(i, j);
+        running += tot;
+        __syncthreads();
+    }
+    if (!WRITE && tid == 0) counts[p] = running;
+    if (WRITE && m2out) {
+        for (int j = tid; j < pr.nB; j += 256) {
+            const u64 kc = colKey[j];
+            m2out[j] = kc ? (int)(0xFFFFFFFFu - (unsigned)kc) : -1;
+        }
+    }
+}
+
+// offsets[first + k + 1] = offsets[first] + sum(counts[0..k]); one block.
+__global__ __launch_bounds__(1024) void match_scan_kernel(const int *__restrict__ counts, int n,
+                                                          int64_t *__restrict__ offsets, int64_t first)
+{
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per, hi = min(n, lo + per);
+    int64_t s = 0;
+    for (int k = lo; k < hi; k++) s += counts[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int64_t v = (tid >= d) ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = offsets[first] + (tid ? part[tid - 1] : 0);
+    for (int k = lo; k < hi; k++) {
+        run += counts[k];
+        offsets[first + k + 1] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct sfm_imageset {
+    sfm_ctx *ctx = nullptr;
+    int n_images = 0;
+    int dim = 0;
+    std::vector<ImageRec> images;
+    std::vector<int> flags;
+    int64_t rows32 = 0, rows16 = 0;
+    DevBuf desc32, desc16, norms, pts, imageRecs, imageFlags;
+    bool owns_desc32 = true, owns_pts = true;
+};
+
+struct sfm_match_result {
+    sfm_ctx *ctx = nullptr;
+    int n_pairs = 0;
+    DevBuf offsets; // int64[n_pairs+1]
+    DevBuf pairs;   // int2[sum min(nA,nB)]
+    DevBuf pairRecs, work, cand, candCount, best, counts, stats, m1, m2;
+    PinBuf hostRecs, hostWork;
+    int64_t total = -1;
+};
+
+extern "C" void sfm_imageset_destroy(sfm_imageset *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->owns_desc32) s->desc32.release();
+    s->desc16.release();
+    s->norms.release();
+    if (s->owns_pts) s->pts.release();
+    s->imageRecs.release();
+    s->imageFlags.release();
+    delete s;
+}
+
+extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
+{
+    if (!s) return 0;
+    return (int64_t)(s->desc32.cap + s->desc16.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
+}
+
+static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, const float *desc,
+                          const double *pts, int dim, bool on_device, sfm_imageset **set_out)
+{
+    if (!ctx || !set_out) return SFM_ERR_INVALID_ARG;
+    *set_out = nullptr;
+    if (n_images < 0 || (n_images > 0 && !counts)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: bad image count");
+    if (dim < 1) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: dim must be >= 1 (was %d)", dim);
+    if (dim > KDIM)
+        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "imageset: descriptor length %d > %d has no kernel", dim, KDIM);
+    if (n_images > 65535) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "imageset: more than 65535 images");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+
+    sfm_imageset *s = new (std::nothrow) sfm_imageset();
+    if (!s) SFM_FAIL(ctx, SFM_ERR_OOM, "imageset: host allocation failed");
+    s->ctx = ctx;
+    s->n_images = n_images;
+    s->dim = dim;
+    s->images.resize(n_images);
+    int maxN = 0;
+    int64_t r32 = 0, r16 = 0;
+    for (int i = 0; i < n_images; i++) {
+        if (counts[i] < 0) {
+            delete s;
+            SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: counts[%d] < 0", i);
+        }
+        s->images[i] = ImageRec{counts[i], 0, r32, r16};
+        r32 += counts[i];
+        r16 += round_up(counts[i], ROW_PAD);
+        if (counts[i] > maxN) maxN = counts[i];
+    }
+    s->rows32 = r32;
+    // one extra padded block so that a B tile or an A block may read past the last image
+    r16 += ROW_PAD;
+    s->rows16 = r16;
+    if (r32 > 0 && (!desc || !pts)) {
+        delete s;
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: null descriptor or point table");
+    }
+
+#define SET_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            sfm_imageset_destroy(s);                                                       \
+            int _code = (_e == hipErrorOutOfMemory) ? SFM_ERR_OOM : SFM_ERR_HIP;           \
+            SFM_FAIL(ctx, _code, "%s failed: %s", #expr, hipGetErrorString(_e));           \
+        }                                                                                  \
+    } while (0)
+
+    const size_t b32 = (size_t)r32 * dim * sizeof(float);
+    const size_t bpts = (size_t)r32 * 2 * sizeof(double);
+    if (on_device) {
+        s->owns_desc32 = false;
+        s->owns_pts = false;
+        s->desc32.p = const_cast<float *>(desc);
+        s->pts.p = const_cast<double *>(pts);
+    } else {
+        SET_HIP(s->desc32.reserve(b32 ? b32 : 16));
+        SET_HIP(s->pts.reserve(bpts ? bpts : 16));
+        if (b32) SET_HIP(hipMemcpyAsync(s->desc32.p, desc, b32, hipMemcpyHostToDevice, ctx->stream));
+        if (bpts) SET_HIP(hipMemcpyAsync(s->pts.p, pts, bpts, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
+    SET_HIP(s->norms.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
+    SET_HIP(s->imageRecs.reserve((size_t)(n_images ? n_images : 1) * sizeof(ImageRec)));
+    SET_HIP(s->imageFlags.reserve((size_t)(n_images ? n_images : 1) * sizeof(int)));
+    SET_HIP(hipMemsetAsync(s->desc16.p, 0, (size_t)r16 * KDIM * sizeof(_Float16), ctx->stream));
+    SET_HIP(hipMemsetAsync(s->imageFlags.p, 0, (size_t)(n_images ? n_images : 1) * sizeof(int), ctx->stream));
+    s->flags.assign(n_images, 0);
+    if (n_images > 0 && maxN > 0) {
+        SET_HIP(hipMemcpyAsync(s->imageRecs.p, s->images.data(), (size_t)n_images * sizeof(ImageRec),
+                               hipMemcpyHostToDevice, ctx->stream));
+        dim3 g1((maxN + 255) / 256, n_images);
+        hipLaunchKernelGGL(ingest_norm_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
+                           s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->imageFlags.as<int>());
+        dim3 g2(((int64_t)maxN * 16 + 255) / 256, n_images);
+        hipLaunchKernelGGL(ingest_f16_kernel, g2, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
+                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->desc16.as<_Float16>());
+        SET_HIP(hipGetLastError());
+        SET_HIP(hipMemcpyAsync(s->flags.data(), s->imageFlags.p, (size_t)n_images * sizeof(int),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SET_HIP(hipStreamSynchronize(ctx->stream));
+#undef SET_HIP
+    *set_out = s;
+    return SFM_OK;
+}
+
+extern "C" int sfm_imageset_create(sfm_ctx *ctx, int n_images, const int32_t *counts, const float *desc,
+                                   const double *pts, int dim, sfm_imageset **set_out)
+{
+    return imageset_build(ctx, n_images, counts, desc, pts, dim, false, set_out);
+}
+
+extern "C" int sfm_imageset_create_device(sfm_ctx *ctx, int n_images, const int32_t *counts,
+                                          const float *desc_device, const double *pts_device, int dim,
+                                          sfm_imageset **set_out)
+{
+    return imageset_build(ctx, n_images, counts, desc_device, pts_device, dim, true, set_out);
+}
+
+extern "C" void sfm_match_result_destroy(sfm_match_result *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount,
+                      &r->best, &r->counts, &r->stats, &r->m1, &r->m2};
+    for (DevBuf *b : bufs) b->release();
+    r->hostRecs.release();
+    r->hostWork.release();
+    delete r;
+}
+
+// shape of the similarity kernel instance in use
+static const int RT_USED = 2;
+static const int WAVES_USED = 8;
+static const int BLOCK_ROWS = WAVES_USED * RT_USED * 32;
+static_assert(BLOCK_ROWS <= ROW_PAD && ROW_PAD % BN == 0, "fp16 row padding must cover a block");
+
+static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
+                            int metric, float threshold, float maxDistSq, sfm_match_result **result_inout,
+                            bool want_m1m2)
+{
+    if (!ctx || !set || !result_inout) return SFM_ERR_INVALID_ARG;
+    if (set->ctx != ctx) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: image set belongs to another context");
+    if (n_pairs < 0 || (n_pairs > 0 && !pair_list)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: bad pair list");
+    if (metric != SFM_METRIC_COSINE && metric != SFM_METRIC_DOT)
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: unknown similarity metric %d", metric);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+
+    sfm_match_result *res = *result_inout;
+    if (!res) {
+        res = new (std::nothrow) sfm_match_result();
+        if (!res) SFM_FAIL(ctx, SFM_ERR_OOM, "match: host allocation failed");
+        res->ctx = ctx;
+        *result_inout = res;
+    } else if (res->ctx != ctx) {
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: result belongs to another context");
+    }
+    res->n_pairs = n_pairs;
+    res->total = -1;
+    sfm_span_reset(ctx, 0);
+
+    const int chunkPairs = (int)std::min<int64_t>(ctx->pairs_per_launch, n_pairs > 0 ? n_pairs : 1);
+    const int candCap = (int)ctx->cand_capacity;
+
+    // --- host records -------------------------------------------------------------------
+    SFM_HIP(ctx, res->hostRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
+    PairRec *recs = res->hostRecs.as<PairRec>();
+    int64_t outTotalCap = 0, maxBest = 0, maxWork = 0;
+    std::vector<int64_t> chunkWorkBase;
+    std::vector<int> chunkWorkCount;
+    int64_t workTotal = 0;
+    int maxNA = 0, maxNB = 0;
+    for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
+        const int c1 = std::min(n_pairs, c0 + chunkPairs);
+        int64_t bestOff = 0;
+        int64_t queueLen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = c0; p < c1; p++) {
+            const int ia = pair_list[2 * p], ib = pair_list[2 * p + 1];
+            if (ia < 0 || ia >= set->n_images || ib < 0 || ib >= set->n_images)
+                SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: pair %d names image %d/%d outside the set", p, ia, ib);
+            const ImageRec &A = set->images[ia], &B = set->images[ib];
+            PairRec &r = recs[p];
+            r.nA = A.n;
+            r.nB = B.n;
+            r.rowA32 = A.row32;
+            r.rowB32 = B.row32;
+            r.rowA16 = A.row16;
+            r.rowB16 = B.row16;
+            r.bestRow = bestOff;
+            r.bestCol = bestOff + A.n;
+            bestOff += (int64_t)A.n + B.n;
+            r.chunkLocal = p - c0;
+            const int wildMask = (metric == SFM_METRIC_COSINE) ? IMG_WILD_COS : IMG_WILD_DOT;
+            const bool wild = ((set->flags[ia] | set->flags[ib]) & wildMask) != 0;
+            const float thrp = threshold > 0.0f ? threshold : 0.0f;
+            if (wild)
+                r.thr_m = -INFINITY;
+            else if (metric == SFM_METRIC_COSINE)
+                r.thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN;
+            else
+                r.thr_m = (thrp == 0.0f) ? -SIM_MARGIN : 0.0f; // DOT with a positive bound tests per cell
+            outTotalCap += std::min(A.n, B.n);
+            queueLen[(p - c0) & 7] += (B.n > 0) ? (A.n + BLOCK_ROWS - 1) / BLOCK_ROWS : 0;
+            maxNA = std::max(maxNA, A.n);
+            maxNB = std::max(maxNB, B.n);
+        }
+        maxBest = std::max(maxBest, bestOff);
+        int64_t qmax = 0;
+        for (int x = 0; x < 8; x++) qmax = std::max(qmax, queueLen[x]);
+        chunkWorkBase.push_back(workTotal);
+        chunkWorkCount.push_back((int)(qmax * 8));
+        workTotal += qmax * 8;
+        maxWork = std::max(maxWork, qmax * 8);
+    }
+
+    // Work list: block b of a chunk takes entry b.  Blocks b and b + 8 run on the same XCD
+    // (round-robin dispatch), so every pair's row blocks are dealt to one residue class mod 8
+    // and share that XCD's L2 copy of image B.
+    SFM_HIP(ctx, res->hostWork.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
+    int2 *work = res->hostWork.as<int2>();
+    {
+        size_t ci = 0;
+        for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
+            const int c1 = std::min(n_pairs, c0 + chunkPairs);
+            int2 *wl = work + chunkWorkBase[ci];
+            const int cnt = chunkWorkCount[ci];
+            for (int k = 0; k < cnt; k++) wl[k] = make_int2(-1, 0);
+            int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int p = c0; p < c1; p++) {
+                const int x = (p - c0) & 7;
+                const int nb = (recs[p].nB > 0) ? (recs[p].nA + BLOCK_ROWS - 1) / BLOCK_ROWS : 0;
+                for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb);
+            }
+        }
+    }
+
+    // --- device buffers -----------------------------------------------------------------
+    SFM_HIP(ctx, res->pairRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
+    SFM_HIP(ctx, res->work.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
+    SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
+    SFM_HIP(ctx, res->pairs.reserve((size_t)(outTotalCap ? outTotalCap : 1) * sizeof(int2)));
+    SFM_HIP(ctx, res->cand.reserve((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)));
+    SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * sizeof(int)));
+    SFM_HIP(ctx, res->best.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(u64)));
+    SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
+    SFM_HIP(ctx, res->stats.reserve(2 * sizeof(u64)));
+    if (want_m1m2) {
+        SFM_HIP(ctx, res->m1.reserve((size_t)(maxNA ? maxNA : 1) * sizeof(int32_t)));
+        SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
+    }
+    hipStream_t st = ctx->stream;
+    if (n_pairs > 0)
+        SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.p, recs, (size_t)n_pairs * sizeof(PairRec), hipMemcpyHostToDevice, st));
+    if (workTotal > 0)
+        SFM_HIP(ctx, hipMemcpyAsync(res->work.p, work, (size_t)workTotal * sizeof(int2), hipMemcpyHostToDevice, st));
+    SFM_HIP(ctx, hipMemsetAsync(res->offsets.p, 0, sizeof(int64_t), st));
+    SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 2 * sizeof(u64), st));
+
+    MatchArgs g;
+    g.desc16 = set->desc16.as<_Float16>();
+    g.desc32 = set->desc32.as<float>();
+    g.norms = set->norms.as<float>();
+    g.pts = set->pts.as<double2>();
+    g.cand = res->cand.as<uint2>();
+    g.candCount = res->candCount.as<int>();
+    g.best = res->best.as<u64>();
+    g.stats = res->stats.as<u64>();
+    g.candCap = candCap;
+    g.dim = set->dim;
+    g.metric = metric;
+    g.threshold = threshold;
+    g.maxDistSq = maxDistSq;
+
+    size_t ci = 0;
+    for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
+        const int c1 = std::min(n_pairs, c0 + chunkPairs);
+        const int np = c1 - c0;
+        g.pairs = res->pairRecs.as<PairRec>() + c0;
+        g.work = res->work.as<int2>() + chunkWorkBase[ci];
+        int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
+        if (bestLen > 0) SFM_HIP(ctx, hipMemsetAsync(res->best.p, 0, (size_t)bestLen * sizeof(u64), st));
+        SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * sizeof(int), st));
+        const int nblk = chunkWorkCount[ci];
+        if (nblk > 0) {
+            SFM_HIP(ctx, sfm_span_begin(ctx, 0));
+            if (metric == SFM_METRIC_COSINE)
+                hipLaunchKernelGGL((match_sim_kernel<RT_USED, WAVES_USED, false>), dim3(nblk), dim3(WAVES_USED * 64), 0, st, g);
+            else
+                hipLaunchKernelGGL((match_sim_kernel<RT_USED, WAVES_USED, true>), dim3(nblk), dim3(WAVES_USED * 64), 0, st, g);
+            SFM_HIP(ctx, sfm_span_end(ctx, 0));
+            if (candCap > 0) {
+                int cb = (candCap + 255) / 256;
+                if (cb > 16) cb = 16;
+                hipLaunchKernelGGL(match_cand_kernel, dim3(cb, np), dim3(256), 0, st, g);
+            }
+        }
+        hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
+                           res->counts.as<int>(), (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr,
+                           (int32_t *)nullptr);
+        hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, res->counts.as<int>(), np,
+                           res->offsets.as<int64_t>(), (int64_t)c0);
+        hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
+                           (int *)nullptr, res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(),
+                           want_m1m2 ? res->m1.as<int32_t>() : nullptr, want_m1m2 ? res->m2.as<int32_t>() : nullptr);
+        SFM_HIP(ctx, hipGetLastError());
+    }
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_batch(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
+                               int metric, float threshold, float max_distance_px_squared,
+                               sfm_match_result **result_inout)
+{
+    return match_batch_impl(ctx, set, pair_list, n_pairs, metric, threshold, max_distance_px_squared,
+                            result_inout, false);
+}
+
+extern "C" int sfm_match_result_total(sfm_match_result *res, int64_t *total_out)
+{
+    if (!res || !total_out) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = res->ctx;
+    if (res->total < 0) {
+        int64_t t = 0;
+        SFM_HIP(ctx, hipMemcpyAsync(&t, res->offsets.as<int64_t>() + res->n_pairs, sizeof t, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        res->total = t;
+    }
+    *total_out = res->total;
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_result_offsets(sfm_match_result *res, int64_t *offsets_out)
+{
+    if (!res || !offsets_out) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = res->ctx;
+    SFM_HIP(ctx, hipMemcpyAsync(offsets_out, res->offsets.p, (size_t)(res->n_pairs + 1) * sizeof(int64_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_result_pairs(sfm_match_result *res, int32_t *pairs_out)
+{
+    if (!res) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = res->ctx;
+    int64_t total = 0;
+    int rc = sfm_match_result_total(res, &total);
+    if (rc != SFM_OK) return rc;
+    if (total == 0) return SFM_OK;
+    if (!pairs_out) return SFM_ERR_INVALID_ARG;
+    SFM_HIP(ctx, hipMemcpyAsync(pairs_out, res->pairs.p, (size_t)total * sizeof(int2), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_result_device(sfm_match_result *res, const int64_t **offsets_device,
+                                       const int32_t **pairs_device)
+{
+    if (!res) return SFM_ERR_INVALID_ARG;
+    if (offsets_device) *offsets_device = res->offsets.as<int64_t>();
+    if (pairs_device) *pairs_device = res->pairs.as<int32_t>();
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_result_stats(sfm_match_result *res, int64_t *candidates_out, int64_t *overflow_out)
+{
+    if (!res) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = res->ctx;
+    u64 s[2] = {0, 0};
+    SFM_HIP(ctx, hipMemcpyAsync(s, res->stats.p, sizeof s, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (candidates_out) *candidates_out = (int64_t)s[0];
+    if (overflow_out) *overflow_out = (int64_t)s[1];
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, const double *ptsA, int nA,
+                              const float *descB, const double *ptsB, int nB, int dim, int metric,
+                              float threshold, float max_distance_px_squared, int32_t *pairs_out, int capacity,
+                              int *count_out, int32_t *matches1_out, int32_t *matches2_out)
+{
+    if (!ctx || !count_out) return SFM_ERR_INVALID_ARG;
+    *count_out = 0;
+    if (algorithm != SFM_MATCH_TWO_SIDED)
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "Match: Unknown matching algorithm. Was %d", algorithm);
+    if (nA < 0 || nB < 0 || capacity < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: negative size");
+    if ((nA > 0 && (!descA || !ptsA)) || (nB > 0 && (!descB || !ptsB)))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: null input");
+
+    // two-image set: A then B
+    const int32_t counts[2] = {nA, nB};
+    std::vector<float> desc((size_t)(nA + nB) * dim);
+    std::vector<double> pts((size_t)(nA + nB) * 2);
+    if (nA) {
+        memcpy(desc.data(), descA, (size_t)nA * dim * sizeof(float));
+        memcpy(pts.data(), ptsA, (size_t)nA * 2 * sizeof(double));
+    }
+    if (nB) {
+        memcpy(desc.data() + (size_t)nA * dim, descB, (size_t)nB * dim * sizeof(float));
+        memcpy(pts.data() + (size_t)nA * 2, ptsB, (size_t)nB * 2 * sizeof(double));
+    }
+    sfm_imageset *set = nullptr;
+    int rc = sfm_imageset_create(ctx, 2, counts, desc.data(), pts.data(), dim, &set);
+    if (rc != SFM_OK) return rc;
+    sfm_match_result *res = nullptr;
+    const int32_t pl[2] = {0, 1};
+    rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &res, true);
+    int64_t total = 0;
+    if (rc == SFM_OK) rc = sfm_match_result_total(res, &total);
+    if (rc == SFM_OK && total > capacity) {
+        ctx->last_error = "match: output capacity too small";
+        rc = SFM_ERR_CAPACITY;
+    }
+    if (rc == SFM_OK && total > 0) rc = sfm_match_result_pairs(res, pairs_out);
+    if (rc == SFM_OK) {
+        *count_out = (int)total;
+        hipError_t e = hipSuccess;
+        if (matches1_out && nA > 0)
+            e = hipMemcpy(matches1_out, res->m1.p, (size_t)nA * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && matches2_out && nB > 0)
+            e = hipMemcpy(matches2_out, res->m2.p, (size_t)nB * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("match: copy of matches1/2 failed: ") + hipGetErrorString(e);
+            rc = SFM_ERR_HIP;
+        }
+    }
+    sfm_match_result_destroy(res);
+    sfm_imageset_destroy(set);
+    return rc;
+}

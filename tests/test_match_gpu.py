@@ -1,0 +1,189 @@
+"""Parity of the HIP matcher (through the C-ABI) with the CPU restatement of
+matchTwoSided (reference submodules/match/match.cpp:24-94).  Bar: bit-exact pair lists
+and bit-exact matches1 / matches2 arrays, for every input class below."""
+import numpy as np
+import pytest
+
+from sfm_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def check_pair(ctx, oracle, dA, pA, dB, pB, thr, gate=1e8, metric=0):
+    got, g1, g2 = ctx.match_pair(dA, pA, dB, pB, threshold=thr, max_dist_sq=gate, metric=metric, return_best=True)
+    exp, e1, e2 = oracle.match(dA, pA, dB, pB, threshold=thr, max_dist_sq=gate, metric=metric)
+    assert np.array_equal(g1, e1), "matches1 differs"
+    assert np.array_equal(g2, e2), "matches2 differs"
+    assert np.array_equal(got, exp), "pair list differs"
+    return got
+
+
+def two_images(nA, nB, kind="sift", seed=3, dim=128, shared=0.3):
+    n = max(nA, nB)
+    d, p, _ = synth.image_set(2, n, dim=dim, shared_frac=shared, seed=seed, kind=kind)
+    return d[:nA].copy(), p[:nA].copy(), d[n:n + nB].copy(), p[n:n + nB].copy()
+
+
+@pytest.mark.parametrize("nA,nB", [(257, 1000), (1000, 257), (2000, 2000), (1, 1), (1, 700), (513, 129)])
+@pytest.mark.parametrize("gate", [1e8, 100.0 * 100.0])
+def test_sift_like(ctx, oracle, nA, nB, gate):
+    dA, pA, dB, pB = two_images(nA, nB)
+    got = check_pair(ctx, oracle, dA, pA, dB, pB, 0.95, gate)
+    if min(nA, nB) >= 257:
+        assert len(got) > 10
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.95, 0.0, -1.0])
+def test_general_float(ctx, oracle, thr):
+    dA, pA, dB, pB = two_images(700, 900, kind="gauss", seed=5)
+    check_pair(ctx, oracle, dA, pA, dB, pB, thr)
+
+
+def test_default_options_all_cells_pass(ctx, oracle):
+    # MATCHING_OPTIONS defaults (threshold 0.5) on SIFT-like data: most cells clear the
+    # threshold, so the arg-max decides everything.
+    dA, pA, dB, pB = two_images(600, 640, shared=0.5)
+    dA = np.maximum(dA, 20)  # raise the floor: cosine of unrelated descriptors ~0.8
+    dB = np.maximum(dB, 20)
+    check_pair(ctx, oracle, dA, pA, dB, pB, 0.5)
+
+
+def test_candidate_list_overflow(ctx, oracle):
+    dA, pA, dB, pB = two_images(500, 500, kind="gauss", seed=9)
+    ctx.set_option("cand_capacity", 64)
+    try:
+        check_pair(ctx, oracle, dA, pA, dB, pB, -1.0)
+        check_pair(ctx, oracle, dA, pA, dB, pB, 0.05)
+        ctx.set_option("cand_capacity", 0)
+        check_pair(ctx, oracle, dA, pA, dB, pB, 0.2)
+    finally:
+        ctx.set_option("cand_capacity", 32768)
+
+
+def test_ties_pick_lowest_index(ctx, oracle):
+    dA, pA, dB, pB = two_images(300, 300)
+    dA[10] = dA[200] = dA[7]          # three identical rows in A
+    dB[5] = dB[99] = dB[250] = dA[7]  # and three copies in B
+    dB[17] = dB[18] = dA[40]
+    got = check_pair(ctx, oracle, dA, pA, dB, pB, 0.9)
+    assert (7, 5) in [tuple(r) for r in got]
+
+
+def test_zero_descriptor_never_matches(ctx, oracle):
+    dA, pA, dB, pB = two_images(200, 200)
+    dA[3] = 0
+    dB[8] = 0
+    for thr in (0.95, 0.0, -1.0):
+        got = check_pair(ctx, oracle, dA, pA, dB, pB, thr)
+        assert 3 not in got[:, 0] and 8 not in got[:, 1]
+
+
+def test_threshold_edge_is_strict(ctx, oracle):
+    dA, pA, dB, pB = two_images(64, 64, shared=1.0)
+    s = np.float32(oracle.similarity(dA[0], dB[np.argmax([oracle.similarity(dA[0], b) for b in dB])]))
+    check_pair(ctx, oracle, dA, pA, dB, pB, float(s))                       # sim == thr must fail
+    check_pair(ctx, oracle, dA, pA, dB, pB, float(np.nextafter(s, np.float32(-1))))
+
+
+def test_pixel_gate_edge_is_strict(ctx, oracle):
+    dA, pA, dB, pB = two_images(50, 50, shared=1.0)
+    pA[:] = 0.0
+    pB[:] = 0.0
+    pB[:, 0] = 3.0
+    pB[:, 1] = 4.0  # squared distance exactly 25
+    assert len(check_pair(ctx, oracle, dA, pA, dB, pB, 0.9, gate=25.0)) == 0
+    assert len(check_pair(ctx, oracle, dA, pA, dB, pB, 0.9, gate=25.000002)) > 0
+
+
+def test_empty_inputs(ctx, oracle):
+    dA, pA, dB, pB = two_images(100, 100)
+    e = np.zeros((0, 128), np.float32)
+    ep = np.zeros((0, 2))
+    assert len(ctx.match_pair(e, ep, dB, pB)) == 0
+    assert len(ctx.match_pair(dA, pA, e, ep)) == 0
+    assert len(ctx.match_pair(e, ep, e, ep)) == 0
+
+
+@pytest.mark.parametrize("dim", [64, 100, 3])
+def test_other_descriptor_lengths(ctx, oracle, dim):
+    dA, pA, dB, pB = two_images(300, 400, dim=dim, kind="gauss", seed=21)
+    check_pair(ctx, oracle, dA, pA, dB, pB, 0.8)
+    check_pair(ctx, oracle, dA, pA, dB, pB, 0.0)
+
+
+@pytest.mark.parametrize("thr", [0.0, 50.0, -3.0])
+def test_dot_metric(ctx, oracle, thr):
+    dA, pA, dB, pB = two_images(300, 280, kind="gauss", seed=8)
+    check_pair(ctx, oracle, dA, pA, dB, pB, thr, metric=capi.METRIC_DOT)
+
+
+def test_dot_metric_sift(ctx, oracle):
+    dA, pA, dB, pB = two_images(300, 280)
+    check_pair(ctx, oracle, dA, pA, dB, pB, 250000.0, metric=capi.METRIC_DOT)
+
+
+def test_extreme_scales(ctx, oracle):
+    dA, pA, dB, pB = two_images(200, 220, kind="gauss", seed=12)
+    dA[:50] *= 1e-18   # squares underflow towards denormals
+    dB[:50] *= 1e15    # squares near overflow
+    dA[60] *= 1e25     # norm overflows to inf
+    dB[70, 0] = np.inf
+    dB[71, 5] = np.nan
+    for metric in (capi.METRIC_COSINE, capi.METRIC_DOT):
+        check_pair(ctx, oracle, dA, pA, dB, pB, 0.3, metric=metric)
+
+
+def test_unknown_algorithm_is_rejected(ctx):
+    dA, pA, dB, pB = two_images(10, 10)
+    with pytest.raises(capi.SfmError) as e:
+        ctx.match_pair(dA, pA, dB, pB, algorithm=7)
+    assert e.value.code == capi.ERR_INVALID_ARG
+
+
+def test_descriptor_too_long_is_rejected(ctx):
+    with pytest.raises(capi.SfmError) as e:
+        ctx.match_pair(np.ones((4, 256), np.float32), np.zeros((4, 2)), np.ones((4, 256), np.float32), np.zeros((4, 2)))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_batch_ragged_exhaustive(ctx, oracle):
+    counts = np.array([300, 0, 513, 1, 1000, 777], np.int32)
+    n = int(counts.max())
+    d, p, _ = synth.image_set(len(counts), n, seed=31)
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)])
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    pl = synth.exhaustive_pairs(len(counts))
+    pl = np.concatenate([pl, pl[:, ::-1], [[2, 2]]]).astype(np.int32)
+    ctx.set_option("pairs_per_launch", 7)  # several chunks
+    try:
+        s = ctx.imageset(counts, desc, pts)
+        res = s.match(pl, threshold=0.95, max_dist_sq=100.0 * 100.0)
+        off, pairs = res.offsets(), res.pairs()
+        res2 = s.match(pl, threshold=0.95, max_dist_sq=100.0 * 100.0, result=res)  # buffer reuse
+        assert np.array_equal(off, res2.offsets()) and np.array_equal(pairs, res2.pairs())
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+    assert off[0] == 0 and len(off) == len(pl) + 1 and off[-1] == len(pairs)
+    for k, (a, b) in enumerate(pl):
+        exp, _, _ = oracle.match(desc[starts[a]:starts[a + 1]], pts[starts[a]:starts[a + 1]],
+                                 desc[starts[b]:starts[b + 1]], pts[starts[b]:starts[b + 1]],
+                                 threshold=0.95, max_dist_sq=100.0 * 100.0)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp), f"pair {k} ({a},{b})"
+    s.close()
+
+
+def test_full_size_properties(ctx):
+    """8192 x 8192 (the benchmark shape): size-independent properties instead of the oracle.
+    Swapping the images transposes the match set; matching an image with itself is the identity
+    on rows with a unique descriptor; results are ascending and one-to-one."""
+    d, p, c = synth.image_set(3, 8192, seed=77)
+    s = ctx.imageset(c, d, p)
+    res = s.match(np.array([[0, 1], [1, 0], [2, 2]], np.int32), threshold=0.95)
+    off, pairs = res.offsets(), res.pairs()
+    ab, ba, cc = pairs[off[0]:off[1]], pairs[off[1]:off[2]], pairs[off[2]:off[3]]
+    assert len(ab) > 2000
+    assert np.all(np.diff(ab[:, 0]) > 0) and len(np.unique(ab[:, 1])) == len(ab)
+    assert set(map(tuple, ab)) == set(map(tuple, ba[:, ::-1]))
+    assert np.array_equal(cc[:, 0], cc[:, 1]) and len(cc) > 8000
+    s.close()
