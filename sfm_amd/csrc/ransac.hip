@@ -1,12 +1,932 @@
-// placeholder until the RANSAC kernels land
+// RANSAC two-view geometry on gfx950: batched 8-point hypotheses and their scoring.
+//
+// What is computed is solve::RANSAC of the reference (submodules/solve/RANSAC.cpp:146-270) with
+// options.model = eightPointAlgorithmFromSubset (solve/eightPoint.cpp:225-372) and the default
+// options.loss (solve/solve.hpp:85-95,119-124), for an explicit table of 8-index sample rows
+// taken in row order:
+//   ransac_prep_kernel   per correspondence: values the reference recomputes per hypothesis
+//                        (K*obs of solve.hpp:91, x2.x2 of the 3x2 normal equations)
+//   ransac_fit_kernel    one hypothesis per lane: 8x9 null vector, 3x3 SVD, the four (R,T)
+//                        candidates and the cheirality vote (eightPoint.cpp:243-344)
+//   ransac_score_kernel  one hypothesis per lane, correspondences staged in LDS and read as
+//                        broadcasts: triangulate (eightPoint.cpp:349-369, with the float cast of
+//                        :365), the two reprojection errors, count and sum inliers in index order
+//   ransac_select_kernel in-order scan with the adaptive cap (RANSAC.cpp:237-258)
+//   ransac_inlier_kernel ascending inlier list of the winner (RANSAC.cpp:213-221)
+//
+// All fp64 arithmetic below is written operation by operation (this file is compiled with
+// contraction off): same products, same sums, same order as the CPU restatement the tests
+// compare against, so counts and error sums agree bit for bit.  Eigen's JacobiSVD and
+// colPivHouseholderQr are replaced by: Householder QR of A^T for the null vector, one-sided
+// Jacobi for the 3x3 SVD, normal equations for the 3x2 least squares.
 #include "common.h"
-struct sfm_ransac_batch { sfm_ctx *ctx; };
-extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *, const double *, int, const double *, const int32_t *, int, int,
-                    double, double, int, int, int32_t *, int, int *, int *, double *, int32_t *, double *, int *) { SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "not built yet"); }
-extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *, const double *, int, const int32_t *, int, double *) { SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "not built yet"); }
-extern "C" int sfm_ransac_batch_run(sfm_ctx *ctx, int, const int64_t *, const double *, const double *, const double *, const int32_t *, int, double, double, int, int, sfm_ransac_batch **) { SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "not built yet"); }
-extern "C" int sfm_ransac_batch_run_device(sfm_ctx *ctx, int, const int64_t *, const double *, const double *, const double *, const int32_t *, int, double, double, int, int, sfm_ransac_batch **) { SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "not built yet"); }
-extern "C" int sfm_ransac_batch_best(sfm_ransac_batch *, int32_t *, int32_t *, double *, double *, int32_t *) { return SFM_ERR_UNSUPPORTED; }
-extern "C" int sfm_ransac_batch_inlier_offsets(sfm_ransac_batch *, int64_t *) { return SFM_ERR_UNSUPPORTED; }
-extern "C" int sfm_ransac_batch_inliers(sfm_ransac_batch *, int32_t *) { return SFM_ERR_UNSUPPORTED; }
-extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *) {}
+
+#pragma clang fp contract(off)
+
+#define SCORE_CH 256 // correspondences staged in LDS per step
+#define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
+
+struct RansacArgs {
+    const double2 *x;
+    const double2 *y;
+    const int64_t *corrOff; // [P+1], device
+    const int32_t *samples; // [P][H][8]
+    double *rec;            // [total][REC_D]
+    double *pose12;         // [P][H][12] R row-major then T
+    int *counts;            // [P][H]
+    double *toterr;         // [P][H]
+    int *bestH;             // [P]
+    int *bestCount;         // [P]
+    double *bestErr;        // [P]
+    int *iterations;        // [P]
+    int *inlCount;          // [P]
+    const int64_t *inlOff;  // [P+1]
+    int32_t *inliers;
+    double K[9]; // column-major
+    double maxSqErr;
+    double successProb;
+    int H;
+    int adaptive;
+    int loss;
+};
+
+// ---------------------------------------------------------------------------------------
+// shared device math (mirrors the CPU restatement's evaluation order)
+// ---------------------------------------------------------------------------------------
+struct Pose {
+    double R[3][3];
+    double T[3];
+};
+
+__device__ __forceinline__ void rot_apply_h(const double R[3][3], double x, double y, double out[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[i] = (R[i][0] * x + R[i][1] * y) + R[i][2];
+}
+
+// Least squares of [-a, b] * lambda = T with b = (x2, y2, 1), bb = b.b, through the normal
+// equations (stands in for colPivHouseholderQr().solve, eightPoint.cpp:321,363).
+__device__ __forceinline__ void triangulate_lambdas(const double a[3], double x2, double y2, double bb,
+                                                    const double T[3], double &l0, double &l1)
+{
+    const double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    const double ab = (a[0] * x2 + a[1] * y2) + a[2];
+    const double aT = (a[0] * T[0] + a[1] * T[1]) + a[2] * T[2];
+    const double bT = (x2 * T[0] + y2 * T[1]) + T[2];
+    const double det = aa * bb - ab * ab;
+    l0 = (ab * bT - bb * aT) / det;
+    l1 = (aa * bT - ab * aT) / det;
+}
+
+// Default loss (solve.hpp:119-124) of one prepared correspondence under pose (R, T).
+__device__ __forceinline__ double reprojection_loss(const double *K, const Pose &P, double x1, double y1,
+                                                    double x2, double y2, double bb, double o1x, double o1y,
+                                                    double o2x, double o2y)
+{
+    double a[3];
+    rot_apply_h(P.R, x1, y1, a);
+    double l0, l1;
+    triangulate_lambdas(a, x2, y2, bb, P.T, l0, l1);
+    const float lambda1 = (float)l0; // eightPoint.cpp:365
+    const double l = (double)lambda1;
+    const double pt0 = l * x1, pt1 = l * y1, pt2 = l;
+    // camera 1, view = identity (solve.hpp:121)
+    double p0 = (K[0] * pt0 + K[3] * pt1) + K[6] * pt2;
+    double p1 = (K[1] * pt0 + K[4] * pt1) + K[7] * pt2;
+    double p2 = (K[2] * pt0 + K[5] * pt1) + K[8] * pt2;
+    p0 = p0 / p2;
+    p1 = p1 / p2;
+    double dx = p0 - o1x, dy = p1 - o1y;
+    const double loss1 = dx * dx + dy * dy;
+    // camera 2, view = [R|T] (solve.hpp:122)
+    const double q0 = ((P.R[0][0] * pt0 + P.R[0][1] * pt1) + P.R[0][2] * pt2) + P.T[0];
+    const double q1 = ((P.R[1][0] * pt0 + P.R[1][1] * pt1) + P.R[1][2] * pt2) + P.T[1];
+    const double q2 = ((P.R[2][0] * pt0 + P.R[2][1] * pt1) + P.R[2][2] * pt2) + P.T[2];
+    p0 = (K[0] * q0 + K[3] * q1) + K[6] * q2;
+    p1 = (K[1] * q0 + K[4] * q1) + K[7] * q2;
+    p2 = (K[2] * q0 + K[5] * q1) + K[8] * q2;
+    p0 = p0 / p2;
+    p1 = p1 / p2;
+    dx = p0 - o2x;
+    dy = p1 - o2y;
+    const double loss2 = dx * dx + dy * dy;
+    return (loss1 < loss2) ? loss2 : loss1; // std::max(loss1, loss2)
+}
+
+// Sampson distance in pixel^2 (extension loss; no counterpart in the reference).
+__device__ __forceinline__ void essential_from_pose(const Pose &P, double E[3][3])
+{
+    const double Tx[3][3] = {{0, -P.T[2], P.T[1]}, {P.T[2], 0, -P.T[0]}, {-P.T[1], P.T[0], 0}};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            E[i][j] = (Tx[i][0] * P.R[0][j] + Tx[i][1] * P.R[1][j]) + Tx[i][2] * P.R[2][j];
+}
+
+__device__ __forceinline__ double sampson_loss(const double *K, const double E[3][3], double x1, double y1,
+                                               double x2, double y2)
+{
+    double Ex1[3], Etx2[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Ex1[i] = (E[i][0] * x1 + E[i][1] * y1) + E[i][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) Etx2[j] = (E[0][j] * x2 + E[1][j] * y2) + E[2][j];
+    const double num = (x2 * Ex1[0] + y2 * Ex1[1]) + Ex1[2];
+    const double den = (Ex1[0] * Ex1[0] + Ex1[1] * Ex1[1]) + (Etx2[0] * Etx2[0] + Etx2[1] * Etx2[1]);
+    const double f = 0.5 * (K[0] + K[4]);
+    return (num * num / den) * (f * f);
+}
+
+// ---------------------------------------------------------------------------------------
+// prep
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, int64_t total)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const double2 a = g.x[k], b = g.y[k];
+    double *r = g.rec + k * REC_D;
+    r[0] = a.x;
+    r[1] = a.y;
+    r[2] = b.x;
+    r[3] = b.y;
+    r[4] = (b.x * b.x + b.y * b.y) + 1.0;
+    r[5] = (g.K[0] * a.x + g.K[3] * a.y) + g.K[6]; // solve.hpp:90-91, obs = K * (ox, oy, 1)
+    r[6] = (g.K[1] * a.x + g.K[4] * a.y) + g.K[7];
+    r[7] = (g.K[0] * b.x + g.K[3] * b.y) + g.K[6];
+    r[8] = (g.K[1] * b.x + g.K[4] * b.y) + g.K[7];
+    r[9] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// fit: one hypothesis per lane
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double det3(const double M[3][3])
+{
+    return (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0])) +
+           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+
+// Unit null vector of the 8x9 matrix whose transpose is B (9x8): Householder QR of B, last
+// column of Q.  Every loop is unrolled so that B lives in registers.
+__device__ __forceinline__ void null_vector_8x9(double B[9][8], double q[9])
+{
+    double tau[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        double sigma = 0.0;
+#pragma unroll
+        for (int r = j; r < 9; r++) sigma = sigma + B[r][j] * B[r][j];
+        const double nrm = sqrt(sigma);
+        if (nrm == 0.0) {
+            tau[j] = 0.0;
+        } else {
+            const double alpha = (B[j][j] > 0.0) ? -nrm : nrm;
+            B[j][j] = B[j][j] - alpha;
+            double vv = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; r++) vv = vv + B[r][j] * B[r][j];
+            tau[j] = 2.0 / vv;
+#pragma unroll
+            for (int c = j + 1; c < 8; c++) {
+                double s = 0.0;
+#pragma unroll
+                for (int r = j; r < 9; r++) s = s + B[r][j] * B[r][c];
+                s = s * tau[j];
+#pragma unroll
+                for (int r = j; r < 9; r++) B[r][c] = B[r][c] - s * B[r][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) q[r] = 0.0;
+    q[8] = 1.0;
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        if (tau[j] != 0.0) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; r++) s = s + B[r][j] * q[r];
+            s = s * tau[j];
+#pragma unroll
+            for (int r = j; r < 9; r++) q[r] = q[r] - s * B[r][j];
+        }
+    }
+    double n2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) n2 = n2 + q[r] * q[r];
+    const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+    for (int r = 0; r < 9; r++) q[r] = q[r] * inv;
+}
+
+template <int P_, int Q_>
+__device__ __forceinline__ bool jacobi_rotate(double G[3][3], double V[3][3])
+{
+    const double alpha = (G[0][P_] * G[0][P_] + G[1][P_] * G[1][P_]) + G[2][P_] * G[2][P_];
+    const double beta = (G[0][Q_] * G[0][Q_] + G[1][Q_] * G[1][Q_]) + G[2][Q_] * G[2][Q_];
+    const double gamma = (G[0][P_] * G[0][Q_] + G[1][P_] * G[1][Q_]) + G[2][P_] * G[2][Q_];
+    if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) return false;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t);
+    const double s = c * t;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double gp = G[i][P_], gq = G[i][Q_];
+        G[i][P_] = c * gp - s * gq;
+        G[i][Q_] = s * gp + c * gq;
+        const double vp = V[i][P_], vq = V[i][Q_];
+        V[i][P_] = c * vp - s * vq;
+        V[i][Q_] = s * vp + c * vq;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void swap_cols(double G[3][3], double V[3][3], double n[3], int a, int b)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double t = G[i][a];
+        G[i][a] = G[i][b];
+        G[i][b] = t;
+        t = V[i][a];
+        V[i][a] = V[i][b];
+        V[i][b] = t;
+    }
+    const double t = n[a];
+    n[a] = n[b];
+    n[b] = t;
+}
+
+// E = U diag(S) V^T, S descending; one-sided Jacobi on the columns of E.
+__device__ __forceinline__ void svd3(const double E[3][3], double U[3][3], double S[3], double V[3][3])
+{
+    double G[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            G[i][j] = E[i][j];
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = jacobi_rotate<0, 1>(G, V);
+        rotated |= jacobi_rotate<0, 2>(G, V);
+        rotated |= jacobi_rotate<1, 2>(G, V);
+        if (!rotated) break;
+    }
+    double nrm[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) nrm[j] = sqrt((G[0][j] * G[0][j] + G[1][j] * G[1][j]) + G[2][j] * G[2][j]);
+    // stable descending order of three values
+    if (nrm[1] > nrm[0]) swap_cols(G, V, nrm, 0, 1);
+    if (nrm[2] > nrm[1]) swap_cols(G, V, nrm, 1, 2);
+    if (nrm[1] > nrm[0]) swap_cols(G, V, nrm, 0, 1);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        S[j] = nrm[j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) U[i][j] = (nrm[j] > 0.0) ? G[i][j] / nrm[j] : 0.0;
+    }
+    const double tiny = 1e-12 * S[0];
+    if (S[0] > 0.0 && S[1] <= tiny) {
+        // rank <= 1: a unit vector orthogonal to u0, built from the axis u0 is least aligned with
+        int m = 0;
+        if (fabs(U[1][0]) < fabs(U[m][0])) m = 1;
+        if (fabs(U[2][0]) < fabs((m == 0) ? U[0][0] : U[1][0])) m = 2;
+        const double ax0 = (m == 0) ? 1.0 : 0.0, ax1 = (m == 1) ? 1.0 : 0.0, ax2 = (m == 2) ? 1.0 : 0.0;
+        const double c0 = U[1][0] * ax2 - U[2][0] * ax1;
+        const double c1 = U[2][0] * ax0 - U[0][0] * ax2;
+        const double c2 = U[0][0] * ax1 - U[1][0] * ax0;
+        const double cn = sqrt((c0 * c0 + c1 * c1) + c2 * c2);
+        U[0][1] = c0 / cn;
+        U[1][1] = c1 / cn;
+        U[2][1] = c2 / cn;
+    }
+    if (S[0] > 0.0 && S[2] <= tiny) {
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+}
+
+__global__ __launch_bounds__(64) void ransac_fit_kernel(const RansacArgs g)
+{
+    const int p = blockIdx.y;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    const int64_t base = g.corrOff[p];
+    const int64_t n = g.corrOff[p + 1] - base;
+    if (h >= g.H || n < 8) return;
+    const int32_t *s = g.samples + ((size_t)p * g.H + h) * 8;
+    int idx[8];
+    bool valid = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        idx[i] = s[i];
+        valid &= idx[i] >= 0 && idx[i] < n;
+    }
+    double *out = g.pose12 + ((size_t)p * g.H + h) * 12;
+    if (!valid) { // a row that names no correspondence scores nothing
+#pragma unroll
+        for (int i = 0; i < 12; i++) out[i] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
+
+    // eightPoint.cpp:243-251: row = [x1*x2, y1*x2, x2, x1*y2, y1*y2, y2, x1, y1, 1]; B = A^T
+    double B[9][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double2 a = g.x[base + idx[i]], b = g.y[base + idx[i]];
+        B[0][i] = a.x * b.x;
+        B[1][i] = a.y * b.x;
+        B[2][i] = b.x;
+        B[3][i] = a.x * b.y;
+        B[4][i] = a.y * b.y;
+        B[5][i] = b.y;
+        B[6][i] = a.x;
+        B[7][i] = a.y;
+        B[8][i] = 1.0;
+    }
+    double q[9];
+    null_vector_8x9(B, q);
+
+    // eightPoint.cpp:257-265
+    const double E[3][3] = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}, {q[6], q[7], q[8]}};
+    double U[3][3], S[3], V[3][3];
+    svd3(E, U, S, V);
+
+    // eightPoint.cpp:274-289: U Rz(+90) has columns (u1, -u0, u2); U Rz(-90) has (-u1, u0, u2)
+    double R1[3][3], R2[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double w = U[i][2] * V[j][2];
+            R1[i][j] = (U[i][1] * V[j][0] - U[i][0] * V[j][1]) + w;
+            R2[i][j] = (U[i][0] * V[j][1] - U[i][1] * V[j][0]) + w;
+        }
+    if (det3(R1) < 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) R1[i][j] = -R1[i][j];
+    }
+    if (det3(R2) < 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) R2[i][j] = -R2[i][j];
+    }
+    const double T12[3] = {U[0][2], U[1][2], U[2][2]};
+
+    // eightPoint.cpp:296-337: cheirality vote over the 8 sample points, first strict maximum
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 8; i++) {
+        const double2 a = g.x[base + idx[i]], b = g.y[base + idx[i]];
+        const double bb = (b.x * b.x + b.y * b.y) + 1.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double sgn = (c & 1) ? -1.0 : 1.0;
+            const double Tc[3] = {sgn * T12[0], sgn * T12[1], sgn * T12[2]};
+            double av[3];
+            rot_apply_h((c < 2) ? R1 : R2, a.x, a.y, av);
+            double l0, l1;
+            triangulate_lambdas(av, b.x, b.y, bb, Tc, l0, l1);
+            if (l0 > 0 && l1 > 0) cnt[c]++;
+        }
+    }
+    int maxIndex = 0, maxPoints = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (cnt[c] > maxPoints) {
+            maxIndex = c;
+            maxPoints = cnt[c];
+        }
+    const double sgn = (maxIndex & 1) ? -1.0 : 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) out[3 * i + j] = (maxIndex < 2) ? R1[i][j] : R2[i][j];
+        out[9 + i] = sgn * T12[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// score: one hypothesis per lane, correspondences broadcast from LDS
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_pose(const double *src, Pose &P)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) P.R[i][j] = src[3 * i + j];
+        P.T[i] = src[9 + i];
+    }
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
+{
+    __shared__ __attribute__((aligned(16))) double rec[SCORE_CH * REC_D];
+    const int p = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x * 256 + tid;
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    const bool active = h < g.H;
+    Pose P;
+    load_pose(g.pose12 + ((size_t)p * g.H + (active ? h : 0)) * 12, P);
+    double E[3][3];
+    if (LOSS == SFM_LOSS_SAMPSON) essential_from_pose(P, E);
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = g.K[i];
+    const double thr = g.maxSqErr;
+
+    int count = 0;
+    double tot = 0.0;
+    for (int k0 = 0; k0 < n; k0 += SCORE_CH) {
+        const int m = min(SCORE_CH, n - k0);
+        const double2 *src = reinterpret_cast<const double2 *>(g.rec + (base + k0) * REC_D);
+        for (int q = tid; q < m * (REC_D / 2); q += 256) reinterpret_cast<double2 *>(rec)[q] = src[q];
+        __syncthreads();
+        for (int kk = 0; kk < m; kk++) {
+            const double *r = rec + kk * REC_D;
+            double e;
+            if (LOSS == SFM_LOSS_SAMPSON)
+                e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+            else
+                e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            if (e < thr) { // RANSAC.cpp:216-220
+                count++;
+                tot += e;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        g.counts[(size_t)p * g.H + h] = count;
+        g.toterr[(size_t)p * g.H + h] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// select: what an in-order worker would keep (RANSAC.cpp:182-186, :229-258)
+// ---------------------------------------------------------------------------------------
+__device__ int safe_cast_to_int(double v) // RANSAC.cpp:14-32
+{
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (int)0x80000000;
+    return (int)v;
+}
+
+#define SEL_TILE 2048
+__global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
+{
+    __shared__ int sc[SEL_TILE];
+    __shared__ double se[SEL_TILE];
+    __shared__ int sDone;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n = (int)(g.corrOff[p + 1] - g.corrOff[p]);
+    int maxIter = g.H, iterationsDone = 0, bestCount = 0, best = -1;
+    double bestError = INFINITY;
+    if (tid == 0) sDone = 0;
+    if (n < 8) { // RANSAC.cpp:148-149
+        if (tid == 0) {
+            g.bestH[p] = -1;
+            g.bestCount[p] = 0;
+            g.bestErr[p] = INFINITY;
+            g.iterations[p] = 0;
+        }
+        return;
+    }
+    for (int t0 = 0; t0 < g.H; t0 += SEL_TILE) {
+        __syncthreads();
+        if (sDone) break;
+        const int m = min(SEL_TILE, g.H - t0);
+        for (int q = tid; q < m; q += 256) {
+            sc[q] = g.counts[(size_t)p * g.H + t0 + q];
+            se[q] = g.toterr[(size_t)p * g.H + t0 + q];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int q = 0; q < m; q++) {
+                if (iterationsDone >= maxIter) {
+                    sDone = 1;
+                    break;
+                }
+                iterationsDone++;
+                const int c = sc[q];
+                const double e = se[q];
+                if (c > 0 && (c > bestCount || (c == bestCount && e < bestError))) {
+                    bestError = e;
+                    bestCount = c;
+                    best = t0 + q;
+                    if (g.adaptive) {
+                        const double inlierRatio = (double)bestCount / (double)n;
+                        const double succesProb = pow(inlierRatio, 8.0);
+                        if (succesProb >= 1e-6) {
+                            const int newMax = safe_cast_to_int(ceil(log(1. - g.successProb) / log(1 - succesProb)));
+                            if (newMax < maxIter) maxIter = newMax;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        g.bestH[p] = best;
+        g.bestCount[p] = bestCount;
+        g.bestErr[p] = bestError;
+        g.iterations[p] = iterationsDone;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// inlier list of the winner, ascending
+// ---------------------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(256) void ransac_inlier_kernel(const RansacArgs g)
+{
+    __shared__ int waveCnt[4];
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int best = g.bestH[p];
+    if (best < 0) {
+        if (!WRITE && tid == 0) g.inlCount[p] = 0;
+        return;
+    }
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    Pose P;
+    load_pose(g.pose12 + ((size_t)p * g.H + best) * 12, P);
+    double E[3][3];
+    essential_from_pose(P, E);
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = g.K[i];
+    int32_t *dst = WRITE ? g.inliers + g.inlOff[p] : nullptr;
+    int running = 0;
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int k = k0 + tid;
+        bool ok = false;
+        if (k < n) {
+            const double *r = g.rec + (base + k) * REC_D;
+            double e;
+            if (g.loss == SFM_LOSS_SAMPSON)
+                e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+            else
+                e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            ok = e < g.maxSqErr;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+        const int prefix = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
+        __syncthreads();
+        int off = running, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) off += waveCnt[w];
+            tot += waveCnt[w];
+        }
+        if (WRITE && ok) dst[off + prefix] = k;
+        running += tot;
+        __syncthreads();
+    }
+    if (!WRITE && tid == 0) g.inlCount[p] = running;
+}
+
+// offsets[k + 1] = sum(counts[0..k]), offsets[0] = 0; one block.
+__global__ __launch_bounds__(1024) void ransac_scan_kernel(const int *__restrict__ counts, int n,
+                                                           int64_t *__restrict__ offsets)
+{
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(n, tid * per), hi = min(n, lo + per);
+    int64_t s = 0;
+    for (int k = lo; k < hi; k++) s += counts[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int64_t v = (tid >= d) ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = tid ? part[tid - 1] : 0;
+    if (tid == 0) offsets[0] = 0;
+    for (int k = lo; k < hi; k++) {
+        run += counts[k];
+        offsets[k + 1] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct sfm_ransac_batch {
+    sfm_ctx *ctx = nullptr;
+    int n_pairs = 0;
+    int H = 0;
+    int64_t total = 0;
+    DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
+        inlOff, inliers;
+};
+
+extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
+                      &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers};
+    for (DevBuf *d : bufs) d->release();
+    delete b;
+}
+
+static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
+                      const double *K, const int32_t *samples, int n_hyp, double maxSqErr, double successProb,
+                      int adaptive, int loss, bool on_device, bool fit_only, sfm_ransac_batch **batch_inout)
+{
+    if (!ctx || !batch_inout) return SFM_ERR_INVALID_ARG;
+    if (n_pairs < 0 || n_hyp < 0 || (n_pairs > 0 && !corr_offsets))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: bad sizes");
+    if (!K) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null K");
+    if (loss != SFM_LOSS_REPROJECTION && loss != SFM_LOSS_SAMPSON)
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: unknown loss %d", loss);
+    if (n_pairs > 65535) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "ransac: more than 65535 pairs per call");
+    int64_t total = 0;
+    if (n_pairs > 0) {
+        if (corr_offsets[0] != 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: offsets must start at 0");
+        for (int p = 0; p < n_pairs; p++) {
+            const int64_t n = corr_offsets[p + 1] - corr_offsets[p];
+            if (n < 0 || n > 0x7FFFFFFF) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: offsets not ascending at pair %d", p);
+        }
+        total = corr_offsets[n_pairs];
+    }
+    if (total > 0 && (!x || !y)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null correspondences");
+    if (n_hyp > 0 && n_pairs > 0 && !samples) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null sample table");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+
+    sfm_ransac_batch *b = *batch_inout;
+    if (!b) {
+        b = new (std::nothrow) sfm_ransac_batch();
+        if (!b) SFM_FAIL(ctx, SFM_ERR_OOM, "ransac: host allocation failed");
+        b->ctx = ctx;
+        *batch_inout = b;
+    } else if (b->ctx != ctx) {
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: batch belongs to another context");
+    }
+    b->n_pairs = n_pairs;
+    b->H = n_hyp;
+    b->total = total;
+    sfm_span_reset(ctx, 1);
+    hipStream_t st = ctx->stream;
+    const size_t PH = (size_t)(n_pairs ? n_pairs : 1) * (size_t)(n_hyp ? n_hyp : 1);
+    const size_t P1 = (size_t)(n_pairs ? n_pairs : 1);
+
+    RansacArgs g;
+    memset(&g, 0, sizeof g);
+    if (on_device) {
+        g.x = reinterpret_cast<const double2 *>(x);
+        g.y = reinterpret_cast<const double2 *>(y);
+        g.samples = samples;
+    } else {
+        SFM_HIP(ctx, b->x.reserve((size_t)(total ? total : 1) * sizeof(double2)));
+        SFM_HIP(ctx, b->y.reserve((size_t)(total ? total : 1) * sizeof(double2)));
+        SFM_HIP(ctx, b->samples.reserve(PH * 8 * sizeof(int32_t)));
+        if (total) {
+            SFM_HIP(ctx, hipMemcpyAsync(b->x.p, x, (size_t)total * sizeof(double2), hipMemcpyHostToDevice, st));
+            SFM_HIP(ctx, hipMemcpyAsync(b->y.p, y, (size_t)total * sizeof(double2), hipMemcpyHostToDevice, st));
+        }
+        if (n_pairs && n_hyp)
+            SFM_HIP(ctx, hipMemcpyAsync(b->samples.p, samples, (size_t)n_pairs * n_hyp * 8 * sizeof(int32_t),
+                                        hipMemcpyHostToDevice, st));
+        g.x = b->x.as<double2>();
+        g.y = b->y.as<double2>();
+        g.samples = b->samples.as<int32_t>();
+    }
+    SFM_HIP(ctx, b->corrOff.reserve((P1 + 1) * sizeof(int64_t)));
+    SFM_HIP(ctx, b->rec.reserve((size_t)(total ? total : 1) * REC_D * sizeof(double)));
+    SFM_HIP(ctx, b->pose12.reserve(PH * 12 * sizeof(double)));
+    SFM_HIP(ctx, b->counts.reserve(PH * sizeof(int)));
+    SFM_HIP(ctx, b->toterr.reserve(PH * sizeof(double)));
+    SFM_HIP(ctx, b->bestH.reserve(P1 * sizeof(int)));
+    SFM_HIP(ctx, b->bestCount.reserve(P1 * sizeof(int)));
+    SFM_HIP(ctx, b->bestErr.reserve(P1 * sizeof(double)));
+    SFM_HIP(ctx, b->iterations.reserve(P1 * sizeof(int)));
+    SFM_HIP(ctx, b->inlCount.reserve(P1 * sizeof(int)));
+    SFM_HIP(ctx, b->inlOff.reserve((P1 + 1) * sizeof(int64_t)));
+    SFM_HIP(ctx, b->inliers.reserve((size_t)(total ? total : 1) * sizeof(int32_t)));
+    if (n_pairs == 0) return SFM_OK;
+    SFM_HIP(ctx, hipMemcpyAsync(b->corrOff.p, corr_offsets, (size_t)(n_pairs + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, st));
+
+    g.corrOff = b->corrOff.as<int64_t>();
+    g.rec = b->rec.as<double>();
+    g.pose12 = b->pose12.as<double>();
+    g.counts = b->counts.as<int>();
+    g.toterr = b->toterr.as<double>();
+    g.bestH = b->bestH.as<int>();
+    g.bestCount = b->bestCount.as<int>();
+    g.bestErr = b->bestErr.as<double>();
+    g.iterations = b->iterations.as<int>();
+    g.inlCount = b->inlCount.as<int>();
+    g.inlOff = b->inlOff.as<int64_t>();
+    g.inliers = b->inliers.as<int32_t>();
+    for (int i = 0; i < 9; i++) g.K[i] = K[i];
+    g.maxSqErr = maxSqErr;
+    g.successProb = successProb;
+    g.H = n_hyp;
+    g.adaptive = adaptive;
+    g.loss = loss;
+
+    if (n_hyp > 0) {
+        // poses of rows that are never fitted (pairs with n < 8) must not be read as garbage
+        SFM_HIP(ctx, hipMemsetAsync(b->pose12.p, 0, (size_t)n_pairs * n_hyp * 12 * sizeof(double), st));
+        hipLaunchKernelGGL(ransac_fit_kernel, dim3((n_hyp + 63) / 64, n_pairs), dim3(64), 0, st, g);
+    }
+    if (!fit_only) {
+        if (total > 0)
+            hipLaunchKernelGGL(ransac_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, total);
+        if (n_hyp > 0) {
+            SFM_HIP(ctx, sfm_span_begin(ctx, 1));
+            if (loss == SFM_LOSS_SAMPSON)
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON>), dim3((n_hyp + 255) / 256, n_pairs),
+                                   dim3(256), 0, st, g);
+            else
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION>), dim3((n_hyp + 255) / 256, n_pairs),
+                                   dim3(256), 0, st, g);
+            SFM_HIP(ctx, sfm_span_end(ctx, 1));
+        }
+        hipLaunchKernelGGL(ransac_select_kernel, dim3(n_pairs), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((ransac_inlier_kernel<false>), dim3(n_pairs), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(1024), 0, st, g.inlCount, n_pairs, b->inlOff.as<int64_t>());
+        hipLaunchKernelGGL((ransac_inlier_kernel<true>), dim3(n_pairs), dim3(256), 0, st, g);
+    }
+    SFM_HIP(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_batch_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x,
+                                    const double *y, const double *K, const int32_t *samples, int n_hyp,
+                                    double max_squared_error, double success_prob, int adaptive, int loss,
+                                    sfm_ransac_batch **batch_inout)
+{
+    return ransac_run(ctx, n_pairs, corr_offsets, x, y, K, samples, n_hyp, max_squared_error, success_prob, adaptive,
+                      loss, false, false, batch_inout);
+}
+
+extern "C" int sfm_ransac_batch_run_device(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets,
+                                           const double *x_device, const double *y_device, const double *K,
+                                           const int32_t *samples_device, int n_hyp, double max_squared_error,
+                                           double success_prob, int adaptive, int loss,
+                                           sfm_ransac_batch **batch_inout)
+{
+    return ransac_run(ctx, n_pairs, corr_offsets, x_device, y_device, K, samples_device, n_hyp, max_squared_error,
+                      success_prob, adaptive, loss, true, false, batch_inout);
+}
+
+#define D2H(dst, buf, bytes)                                                                             \
+    do {                                                                                                 \
+        if ((dst) && (bytes) > 0)                                                                        \
+            SFM_HIP(ctx, hipMemcpyAsync((dst), (buf).p, (bytes), hipMemcpyDeviceToHost, ctx->stream));   \
+    } while (0)
+
+extern "C" int sfm_ransac_batch_best(sfm_ransac_batch *b, int32_t *best_hyp_out, int32_t *best_count_out,
+                                     double *best_toterr_out, double *pose12_out, int32_t *iterations_out)
+{
+    if (!b) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    const size_t P = (size_t)b->n_pairs;
+    std::vector<int32_t> bh(P ? P : 1);
+    SFM_HIP(ctx, hipMemcpyAsync(bh.data(), b->bestH.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    D2H(best_count_out, b->bestCount, P * sizeof(int32_t));
+    D2H(best_toterr_out, b->bestErr, P * sizeof(double));
+    D2H(iterations_out, b->iterations, P * sizeof(int32_t));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (best_hyp_out) memcpy(best_hyp_out, bh.data(), P * sizeof(int32_t));
+    if (pose12_out) {
+        for (size_t p = 0; p < P; p++) {
+            if (bh[p] >= 0) {
+                SFM_HIP(ctx, hipMemcpyAsync(pose12_out + 12 * p,
+                                            b->pose12.as<double>() + ((size_t)p * b->H + bh[p]) * 12,
+                                            12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            } else {
+                for (int i = 0; i < 12; i++) pose12_out[12 * p + i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+            }
+        }
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_batch_inlier_offsets(sfm_ransac_batch *b, int64_t *offsets_out)
+{
+    if (!b || !offsets_out) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    if (b->n_pairs == 0) {
+        offsets_out[0] = 0;
+        return SFM_OK;
+    }
+    D2H(offsets_out, b->inlOff, (size_t)(b->n_pairs + 1) * sizeof(int64_t));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_batch_inliers(sfm_ransac_batch *b, int32_t *inliers_out)
+{
+    if (!b) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    if (b->n_pairs == 0) return SFM_OK;
+    int64_t tot = 0;
+    SFM_HIP(ctx, hipMemcpyAsync(&tot, b->inlOff.as<int64_t>() + b->n_pairs, sizeof tot, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (tot > 0) {
+        if (!inliers_out) return SFM_ERR_INVALID_ARG;
+        D2H(inliers_out, b->inliers, (size_t)tot * sizeof(int32_t));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, int n, const double *K,
+                               const int32_t *samples, int n_hyp, int min_n, double max_squared_error,
+                               double success_prob, int adaptive, int loss, int32_t *inliers_out, int capacity,
+                               int *count_out, int *best_hyp_out, double *pose_out, int32_t *counts_out,
+                               double *toterr_out, int *iterations_out)
+{
+    if (!ctx || !count_out) return SFM_ERR_INVALID_ARG;
+    *count_out = 0;
+    if (best_hyp_out) *best_hyp_out = -1;
+    if (iterations_out) *iterations_out = 0;
+    if (n < 0 || n_hyp < 0 || capacity < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: negative size");
+    if (min_n != 8)
+        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "ransac: minN = %d has no kernel (the 8-point model needs exactly 8)", min_n);
+    if (n < min_n) return SFM_OK; // RANSAC.cpp:148-149
+    const int64_t off[2] = {0, n};
+    sfm_ransac_batch *b = nullptr;
+    int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, max_squared_error, success_prob, adaptive, loss, false,
+                        false, &b);
+    int32_t bh = -1, bc = 0, it = 0;
+    double be = 0, pose12[12];
+    if (rc == SFM_OK) rc = sfm_ransac_batch_best(b, &bh, &bc, &be, pose12, &it);
+    if (rc == SFM_OK && bc > capacity) {
+        ctx->last_error = "ransac: inlier capacity too small";
+        rc = SFM_ERR_CAPACITY;
+    }
+    if (rc == SFM_OK && bc > 0) rc = sfm_ransac_batch_inliers(b, inliers_out);
+    if (rc == SFM_OK) {
+        *count_out = bc;
+        if (best_hyp_out) *best_hyp_out = bh;
+        if (iterations_out) *iterations_out = it;
+        if (pose_out) { // 4x4 column-major [R|T; 0 0 0 1]
+            for (int c = 0; c < 4; c++)
+                for (int r = 0; r < 4; r++) pose_out[r + 4 * c] = (r == c) ? 1.0 : 0.0;
+            if (bh >= 0)
+                for (int r = 0; r < 3; r++) {
+                    for (int c = 0; c < 3; c++) pose_out[r + 4 * c] = pose12[3 * r + c];
+                    pose_out[r + 12] = pose12[9 + r];
+                }
+        }
+        hipError_t e = hipSuccess;
+        if (counts_out && n_hyp > 0)
+            e = hipMemcpy(counts_out, b->counts.p, (size_t)n_hyp * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && toterr_out && n_hyp > 0)
+            e = hipMemcpy(toterr_out, b->toterr.p, (size_t)n_hyp * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("ransac: copy of per-hypothesis scores failed: ") + hipGetErrorString(e);
+            rc = SFM_ERR_HIP;
+        }
+    }
+    sfm_ransac_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n, const int32_t *samples,
+                                   int n_hyp, double *pose12_out)
+{
+    if (!ctx) return SFM_ERR_INVALID_ARG;
+    if (n < 8) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG,
+                        "EightPointFromSubset: There have to be at least 8 pair-to-pair-correspondences (was: %d)", n);
+    if (n_hyp < 0 || (n_hyp > 0 && !pose12_out)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "fit: bad output");
+    const int64_t off[2] = {0, n};
+    const double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    sfm_ransac_batch *b = nullptr;
+    int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, true, &b);
+    if (rc == SFM_OK && n_hyp > 0) {
+        hipError_t e = hipMemcpyAsync(pose12_out, b->pose12.p, (size_t)n_hyp * 12 * sizeof(double),
+                                      hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("fit: copy failed: ") + hipGetErrorString(e);
+            rc = SFM_ERR_HIP;
+        }
+    }
+    sfm_ransac_batch_destroy(b);
+    return rc;
+}

@@ -1,0 +1,178 @@
+"""Parity of the HIP RANSAC path (through the C-ABI) with the CPU restatement of
+solve::RANSAC + eightPointAlgorithmFromSubset + the default loss (reference
+submodules/solve/RANSAC.cpp:146-270, eightPoint.cpp:225-372, solve.hpp:85-95,119-124).
+Bar: identical inlier sets, identical per-hypothesis inlier counts, identical winner,
+models within 1e-6 (observed: bit-identical poses and error sums)."""
+import numpy as np
+import pytest
+
+from sfm_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_run(got, exp, pose_tol=1e-6):
+    assert np.array_equal(got["counts"], exp["counts"]), "per-hypothesis inlier counts differ"
+    assert got["best_h"] == exp["best_h"]
+    assert got["iterations"] == exp["iterations"]
+    assert np.array_equal(got["inliers"], exp["inliers"]), "inlier sets differ"
+    assert np.allclose(got["toterr"], exp["toterr"], rtol=1e-12, atol=0), "error sums differ"
+    assert np.abs(got["pose"] - exp["pose"]).max() <= pose_tol
+
+
+@pytest.mark.parametrize("n,H", [(8, 16), (64, 256), (2000, 1024), (333, 100)])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_ransac_pair_matches_restatement(ctx, oracle, n, H, adaptive):
+    tv = synth.two_view(n, inlier_ratio=0.5 if n < 100 else 0.3, seed=100 + n)
+    S = synth.sample_table(n, H, seed=n)
+    got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=adaptive)
+    exp = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=adaptive)
+    assert_same_run(got, exp)
+
+
+def test_ransac_stress_ratio(ctx, oracle):
+    # 15 % inliers (the RANSAC stress shape, scaled down): the adaptive cap never applies
+    tv = synth.two_view(3000, inlier_ratio=0.15, seed=5)
+    S = synth.sample_table(3000, 2048, seed=6)
+    got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    exp = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    assert_same_run(got, exp)
+    assert got["iterations"] == 2048
+
+
+def test_poses_bit_identical_to_restatement(ctx, oracle):
+    tv = synth.two_view(500, inlier_ratio=0.6, seed=9)
+    S = synth.sample_table(500, 512, seed=10)
+    got = ctx.eight_point_fit(tv["x"], tv["y"], S)
+    exp, _ = oracle.fit_hypotheses(tv["x"], tv["y"], S)
+    assert np.abs(got - exp).max() <= 1e-9
+    same = np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+    print("poses bit-identical:", same)
+    # every pose is a rotation and a unit translation
+    R = got[:, :9].reshape(-1, 3, 3)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-9)
+    assert np.allclose(np.linalg.det(R), 1.0, atol=1e-9)
+    assert np.allclose(np.linalg.norm(got[:, 9:], axis=1), 1.0, atol=1e-9)
+
+
+def test_sampson_loss(ctx, oracle):
+    tv = synth.two_view(800, inlier_ratio=0.4, seed=3)
+    S = synth.sample_table(800, 256, seed=4)
+    got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, adaptive=False, loss=capi.LOSS_SAMPSON)
+    exp = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, adaptive=False, loss_kind=1)
+    assert_same_run(got, exp)
+
+
+def test_loss_special_values(ctx, oracle):
+    """Degenerate correspondences: identical points (parallel rays, det = 0 -> NaN/inf depth),
+    a point at the epipole; the loss's NaN rules (std::max keeps loss1 when loss2 is NaN) decide."""
+    tv = synth.two_view(200, inlier_ratio=0.7, seed=13)
+    x, y = tv["x"].copy(), tv["y"].copy()
+    x[5] = y[5] = [0.0, 0.0]
+    x[6] = [0.1, 0.2]
+    y[6] = [0.1, 0.2]
+    x[7] = [1e8, -1e8]
+    y[8] = [np.inf, 0.0]
+    x[9] = [np.nan, 0.0]
+    S = synth.sample_table(200, 200, seed=2)
+    S = S[~np.isin(S, [7, 8, 9]).any(axis=1)]
+    got = ctx.ransac_pair(x, y, tv["K"], S, max_sq_err=1.0, adaptive=False)
+    exp = oracle.ransac(x, y, tv["K"], S, max_sq_err=1.0, adaptive=False)
+    assert_same_run(got, exp)
+
+
+def test_guards(ctx):
+    tv = synth.two_view(7, inlier_ratio=1.0, seed=1)
+    S = np.zeros((4, 8), np.int32)
+    r = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S)
+    assert len(r["inliers"]) == 0 and r["best_h"] == -1          # RANSAC.cpp:148-149
+    r = ctx.ransac_pair(tv["x"], tv["y"][:5], tv["K"], S)
+    assert len(r["inliers"]) == 0
+    tv = synth.two_view(20, inlier_ratio=1.0, seed=1)
+    with pytest.raises(capi.SfmError) as e:
+        ctx.ransac_pair(tv["x"], tv["y"], tv["K"], np.zeros((4, 9), np.int32), min_n=9)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_no_hypothesis_with_inliers(ctx, oracle):
+    rng = np.random.default_rng(0)
+    x, y = rng.uniform(-0.5, 0.5, (50, 2)), rng.uniform(-0.5, 0.5, (50, 2))
+    S = synth.sample_table(50, 32, seed=1)
+    got = ctx.ransac_pair(x, y, synth.default_K(), S, max_sq_err=1e-12, adaptive=True)
+    exp = oracle.ransac(x, y, synth.default_K(), S, max_sq_err=1e-12, adaptive=True)
+    assert_same_run(got, exp)
+
+
+def test_batch_ragged(ctx, oracle):
+    sizes = [500, 7, 64, 1500, 8, 0, 900]
+    H = 192
+    xs, ys, Ss, off = [], [], [], [0]
+    for k, n in enumerate(sizes):
+        if n >= 8:
+            tv = synth.two_view(n, inlier_ratio=0.4, seed=40 + k)
+            xs.append(tv["x"]); ys.append(tv["y"])
+            Ss.append(synth.sample_table(n, H, seed=50 + k))
+        else:
+            xs.append(np.zeros((n, 2))); ys.append(np.zeros((n, 2)))
+            Ss.append(np.zeros((H, 8), np.int32))
+        off.append(off[-1] + n)
+    K = synth.default_K()
+    b = ctx.ransac_batch(off, np.concatenate(xs), np.concatenate(ys), K, np.concatenate(Ss), H, max_sq_err=1.0,
+                         success_prob=0.99, adaptive=True)
+    best = b.best()
+    ioff, inl = b.inliers()
+    for k, n in enumerate(sizes):
+        exp = oracle.ransac(xs[k], ys[k], K, Ss[k], max_sq_err=1.0, success_prob=0.99, adaptive=True)
+        assert best["best_h"][k] == exp["best_h"], k
+        assert best["count"][k] == len(exp["inliers"])
+        assert np.array_equal(inl[ioff[k]:ioff[k + 1]], exp["inliers"])
+        if n >= 8:
+            assert best["iterations"][k] == exp["iterations"]
+            assert np.abs(best["pose12"][k, :9].reshape(3, 3) - exp["pose"][:3, :3]).max() <= 1e-6
+            assert np.abs(best["pose12"][k, 9:] - exp["pose"][:3, 3]).max() <= 1e-6
+    b.close()
+
+
+def test_full_size_recovers_planted_pose(ctx):
+    """20 000 correspondences x 4096 hypotheses (the RANSAC stress shape) at 60 % inliers, where
+    all-inlier samples exist: properties instead of the oracle.  The winner's inliers are planted
+    ones, the pose is the planted pose up to the accuracy of an 8-point fit, the list is ascending,
+    and a batch of copies of the pair gives the same answer for every copy."""
+    n, H = 20000, 4096
+    tv = synth.two_view(n, inlier_ratio=0.6, seed=77)
+    S = synth.sample_table(n, H, seed=78)
+    r = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=4.0, success_prob=0.999, adaptive=False)
+    inl = r["inliers"]
+    truth = tv["inlier_mask"]
+    assert len(inl) > 0.2 * truth.sum()
+    assert truth[inl].mean() > 0.9
+    assert np.all(np.diff(inl) > 0)
+    assert len(inl) == r["counts"].max() == r["counts"][r["best_h"]]
+    R, T = r["pose"][:3, :3], r["pose"][:3, 3]
+    ang = np.degrees(np.arccos(np.clip((np.trace(R @ tv["R"].T) - 1) / 2, -1, 1)))
+    assert ang < 5.0 and abs(T @ tv["T"]) > 0.9
+    off = np.arange(4) * n
+    b = ctx.ransac_batch(off, np.tile(tv["x"], (3, 1)), np.tile(tv["y"], (3, 1)), tv["K"], np.tile(S, (3, 1)), H,
+                         max_sq_err=4.0, success_prob=0.999, adaptive=False)
+    best = b.best()
+    ioff, binl = b.inliers()
+    for k in range(3):
+        assert best["best_h"][k] == r["best_h"] and np.array_equal(binl[ioff[k]:ioff[k + 1]], inl)
+    b.close()
+
+
+def test_stress_shape_is_deterministic(ctx):
+    """The 15 % / 20 000 / 4096 shape itself: no all-inlier sample is expected, so only
+    run-to-run identity and the selection rule (max count, then min error, then first) are checked."""
+    n, H = 20000, 4096
+    tv = synth.two_view(n, inlier_ratio=0.15, seed=5)
+    S = synth.sample_table(n, H, seed=6)
+    a = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    b = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    assert a["iterations"] == H  # w^8 < 1e-6: the cap of RANSAC.cpp:248 never applies
+    assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["toterr"], b["toterr"])
+    assert np.array_equal(a["inliers"], b["inliers"]) and a["best_h"] == b["best_h"]
+    c = a["counts"]
+    top = np.flatnonzero(c == c.max())
+    assert a["best_h"] == top[np.argmin(a["toterr"][top])]
+    assert len(a["inliers"]) == c.max()
