@@ -1,0 +1,105 @@
+"""Multi-GPU sharding of the pair list: one process per GPU, a static partition of the image
+pairs, and a gather of the per-rank CSR match lists to rank 0.
+
+Pairs are independent (the reference's match() and RANSAC() read only their own two images,
+submodules/scene.cpp:60,261), so the data path has no collective; the only exchange is the final
+gather of results.  With torch.distributed's "nccl" backend that gather runs as concurrent
+point-to-point transfers over xGMI (RCCL); the CPU tests use "gloo".
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def partition_pairs(n_pairs: int, rank: int, world: int, block: int = 64) -> np.ndarray:
+    """Indices (ascending) of the pairs rank owns: blocks of `block` consecutive pairs dealt
+    round-robin, so ranks differ by at most one block and consecutive pairs (which share an
+    image in an exhaustive list) stay on one GPU."""
+    if world <= 1:
+        return np.arange(n_pairs, dtype=np.int64)
+    idx = np.arange(n_pairs, dtype=np.int64)
+    return idx[(idx // block) % world == rank]
+
+
+def images_for_pairs(n_pairs: int) -> int:
+    """Smallest n with n*(n-1)/2 >= n_pairs."""
+    n = int(np.ceil((1 + np.sqrt(1 + 8.0 * n_pairs)) / 2))
+    while n * (n - 1) // 2 < n_pairs:
+        n += 1
+    while n > 2 and (n - 1) * (n - 2) // 2 >= n_pairs:
+        n -= 1
+    return n
+
+
+class DevicePtrView:
+    """Zero-copy view of library-owned device memory for torch.as_tensor()."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def gather_csr(counts, payload, n_pairs_total: int, rank: int, world: int, block: int = 64,
+               width: int = 2, device=None) -> Optional[Tuple[np.ndarray, "object"]]:
+    """Gather per-rank CSR lists to rank 0.
+
+    counts: torch int64 tensor [owned pairs] (entries per owned pair, on `device`);
+    payload: torch int32 tensor [sum(counts), width] on `device`.
+    Returns on rank 0 (offsets int64 numpy [n_pairs_total+1], payload tensor in global pair
+    order); None elsewhere.  Uses torch.distributed send/recv (RCCL over xGMI with the nccl
+    backend: rank 0 posts all receives at once, one per peer link)."""
+    import torch
+    import torch.distributed as dist
+
+    if world <= 1:
+        c = counts.cpu().numpy()
+        off = np.zeros(n_pairs_total + 1, np.int64)
+        np.cumsum(c, out=off[1:])
+        return off, payload
+
+    owned = [partition_pairs(n_pairs_total, r, world, block) for r in range(world)]
+    max_owned = max(len(o) for o in owned)
+    # step 1: per-pair counts of every rank (fixed-size all_gather)
+    mine = torch.zeros(max_owned, dtype=torch.int64, device=counts.device)
+    mine[:len(counts)] = counts
+    all_counts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(all_counts, mine)
+    # step 2: payloads to rank 0, all peers at once
+    if rank != 0:
+        if payload.numel() > 0:
+            dist.send(payload.contiguous(), dst=0)
+        return None
+    per_rank_counts = [all_counts[r][:len(owned[r])].cpu().numpy() for r in range(world)]
+    bufs, ops = [payload], []
+    for r in range(1, world):
+        tot = int(per_rank_counts[r].sum())
+        buf = torch.empty((tot, width), dtype=payload.dtype, device=payload.device)
+        bufs.append(buf)
+        if tot > 0:
+            ops.append(dist.P2POp(dist.irecv, buf, r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    # step 3: global CSR in pair order
+    global_counts = np.zeros(n_pairs_total, np.int64)
+    for r in range(world):
+        global_counts[owned[r]] = per_rank_counts[r]
+    off = np.zeros(n_pairs_total + 1, np.int64)
+    np.cumsum(global_counts, out=off[1:])
+    out = torch.empty((int(off[-1]), width), dtype=payload.dtype, device=payload.device)
+    for r in range(world):
+        if len(owned[r]) == 0:
+            continue
+        src_off = np.zeros(len(owned[r]) + 1, np.int64)
+        np.cumsum(per_rank_counts[r], out=src_off[1:])
+        # consecutive owned pairs of one block are contiguous on both sides: copy block-wise
+        starts = np.flatnonzero(np.diff(np.concatenate([[-2], owned[r]])) != 1)
+        ends = np.concatenate([starts[1:], [len(owned[r])]])
+        for s, e in zip(starts, ends):
+            a, b = int(src_off[s]), int(src_off[e])
+            if b > a:
+                d0 = int(off[owned[r][s]])
+                out[d0:d0 + (b - a)] = bufs[r][a:b]
+    return off, out
