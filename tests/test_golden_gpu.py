@@ -1,0 +1,30 @@
+"""The HIP path (through the C-ABI) against the committed golden vectors in tests/golden/."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "match_*.npz"))), ids=os.path.basename)
+def test_matcher_golden(ctx, path):
+    g = np.load(path)
+    pairs, m1, m2 = ctx.match_pair(g["descA"], g["ptsA"], g["descB"], g["ptsB"], threshold=float(g["threshold"]),
+                                   max_dist_sq=float(g["max_dist_sq"]), metric=int(g["metric"]), return_best=True)
+    assert np.array_equal(pairs, g["pairs"]) and np.array_equal(m1, g["matches1"]) and np.array_equal(m2, g["matches2"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ransac_*.npz"))), ids=os.path.basename)
+def test_ransac_golden(ctx, path):
+    g = np.load(path)
+    r = ctx.ransac_pair(g["x"], g["y"], g["K"], g["samples"], max_sq_err=float(g["max_sq_err"]),
+                        success_prob=float(g["success_prob"]), adaptive=bool(g["adaptive"]))
+    assert np.array_equal(r["inliers"], g["inliers"]) and r["best_h"] == int(g["best_h"])
+    assert np.array_equal(r["counts"], g["counts"]) and r["iterations"] == int(g["iterations"])
+    assert np.allclose(r["toterr"], g["toterr"], rtol=1e-12, atol=0)
+    assert np.abs(r["pose"] - g["pose"]).max() <= 1e-6
+    pose12 = ctx.eight_point_fit(g["x"], g["y"], g["samples"])
+    assert np.abs(pose12 - g["pose12"]).max() <= 1e-6

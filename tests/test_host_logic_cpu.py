@@ -1,0 +1,92 @@
+"""Host-side logic that needs no GPU: option structs mirror the reference's defaults, the plug-in
+points reject user functors, pair-list partitioning, synthetic generators."""
+import numpy as np
+import pytest
+
+import sfm_amd
+from sfm_amd import api, shard, synth
+
+
+def test_option_defaults_mirror_the_reference():
+    m = sfm_amd.MATCHING_OPTIONS()        # match/match.hpp:55-61
+    assert (m.algorithm, m.threshold, m.maxDistancePxSquared) == (0, 0.5, 1e8)
+    assert m.similarityMetric is sfm_amd.cosineSimilarity
+    r = sfm_amd.RANSAC_OPTIONS()          # solve/solve.hpp:108-125
+    assert (r.minN, r.maxIter, r.maxTimeMs, r.maxSquaredError, r.successProb) == (8, 512, 1000, 10.0, 0.99)
+    assert r.model is api.eightPointAlgorithmFromSubset and r.loss is api.defaultLoss
+
+
+def test_unknown_algorithm_raises_like_the_reference():
+    with pytest.raises(ValueError, match="Unknown matching algorithm"):   # match.cpp:18
+        sfm_amd.match([], [], sfm_amd.MATCHING_OPTIONS(algorithm=3))
+
+
+def test_user_functors_have_no_kernel():
+    with pytest.raises(NotImplementedError):
+        sfm_amd.match([], [], sfm_amd.MATCHING_OPTIONS(similarityMetric=lambda a, b: 0.0))
+    x = np.zeros((9, 2))
+    with pytest.raises(NotImplementedError):
+        sfm_amd.RANSAC(x, x, np.eye(3), sfm_amd.RANSAC_OPTIONS(model=lambda *a: None))
+    with pytest.raises(NotImplementedError):
+        sfm_amd.RANSAC(x, x, np.eye(3), sfm_amd.RANSAC_OPTIONS(loss=lambda *a: 0.0))
+
+
+def test_ransac_guard_returns_empty():
+    x = np.zeros((7, 2))
+    assert sfm_amd.RANSAC(x, x, np.eye(3)) == []                  # RANSAC.cpp:148-149
+    assert sfm_amd.RANSAC(np.zeros((9, 2)), np.zeros((8, 2)), np.eye(3)) == []
+
+
+def test_safe_cast_to_int():
+    assert api.safeCastToInt(float("nan")) == 0
+    assert api.safeCastToInt(1e300) == 2147483647 and api.safeCastToInt(-1e300) == -2147483648
+    assert api.safeCastToInt(12.9) == 12 and api.safeCastToInt(float("inf")) == 2147483647
+
+
+@pytest.mark.parametrize("n,world", [(0, 2), (1, 2), (63, 2), (64, 2), (1000, 2), (19900, 8), (130, 4)])
+def test_partition_is_a_partition(n, world):
+    parts = [shard.partition_pairs(n, r, world) for r in range(world)]
+    allidx = np.sort(np.concatenate(parts)) if n else np.zeros(0, np.int64)
+    assert np.array_equal(allidx, np.arange(n))
+    sizes = [len(p) for p in parts]
+    assert max(sizes) - min(sizes) <= 64
+    for p in parts:
+        assert np.all(np.diff(p) > 0)
+
+
+def test_images_for_pairs():
+    for n_pairs in (1, 3, 19900, 39800, 79600, 159200):
+        n = shard.images_for_pairs(n_pairs)
+        assert n * (n - 1) // 2 >= n_pairs > (n - 1) * (n - 2) // 2
+    assert shard.images_for_pairs(19900) == 200
+
+
+def test_exhaustive_pairs():
+    p = synth.exhaustive_pairs(200)
+    assert p.shape == (19900, 2) and np.all(p[:, 0] < p[:, 1])
+    assert len({tuple(r) for r in p}) == 19900
+
+
+def test_sample_table_rows_are_distinct_and_in_range():
+    for n in (8, 20, 300, 20000):
+        S = synth.sample_table(n, 500, seed=n)
+        assert S.shape == (500, 8) and S.min() >= 0 and S.max() < n
+        assert all(len(set(r)) == 8 for r in S)
+    assert np.array_equal(synth.sample_table(1000, 10, seed=5), synth.sample_table(1000, 10, seed=5))
+
+
+def test_sift_like_descriptors_are_exact_in_fp16_mfma():
+    d = synth.sift_like(np.random.default_rng(0), 1000)
+    assert d.dtype == np.float32 and np.array_equal(d, np.rint(d)) and d.min() >= 0 and d.max() <= 255
+    assert (d.astype(np.float64) ** 2).sum(axis=1).max() < 2 ** 24
+
+
+def test_two_view_geometry_is_consistent():
+    tv = synth.two_view(500, inlier_ratio=0.4, seed=3, noise_px=0.0)
+    x = np.concatenate([tv["x"], np.ones((500, 1))], axis=1)
+    y = np.concatenate([tv["y"], np.ones((500, 1))], axis=1)
+    T = tv["T"]
+    E = np.array([[0, -T[2], T[1]], [T[2], 0, -T[0]], [-T[1], T[0], 0]]) @ tv["R"]
+    res = np.abs(np.einsum("ni,ij,nj->n", y, E, x))
+    assert res[tv["inlier_mask"]].max() < 1e-9 and np.median(res[~tv["inlier_mask"]]) > 1e-3
+    assert tv["inlier_mask"].sum() == 200

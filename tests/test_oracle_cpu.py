@@ -1,0 +1,250 @@
+"""CPU checks of the restatement in oracle/: against the committed golden vectors, against an
+independent numpy evaluation of the same fp32 operation sequence, and against LAPACK for the
+linear algebra that stands in for Eigen.  (The reference ships no fixtures: parity unpinned.)"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from sfm_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(prefix):
+    files = sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+    assert files, f"no golden files for {prefix}"
+    return files
+
+
+@pytest.mark.parametrize("path", golden("match_"), ids=os.path.basename)
+def test_matcher_golden(oracle, path):
+    g = np.load(path)
+    pairs, m1, m2 = oracle.match(g["descA"], g["ptsA"], g["descB"], g["ptsB"], threshold=float(g["threshold"]),
+                                 max_dist_sq=float(g["max_dist_sq"]), metric=int(g["metric"]))
+    assert np.array_equal(pairs, g["pairs"]) and np.array_equal(m1, g["matches1"]) and np.array_equal(m2, g["matches2"])
+
+
+@pytest.mark.parametrize("path", golden("ransac_"), ids=os.path.basename)
+def test_ransac_golden(oracle, path):
+    g = np.load(path)
+    r = oracle.ransac(g["x"], g["y"], g["K"], g["samples"], max_sq_err=float(g["max_sq_err"]),
+                      success_prob=float(g["success_prob"]), adaptive=bool(g["adaptive"]))
+    assert np.array_equal(r["inliers"], g["inliers"]) and r["best_h"] == int(g["best_h"])
+    assert np.array_equal(r["counts"], g["counts"]) and np.array_equal(r["toterr"], g["toterr"])
+    assert r["iterations"] == int(g["iterations"]) and np.array_equal(r["pose"], g["pose"])
+    pose12, cand = oracle.fit_hypotheses(g["x"], g["y"], g["samples"])
+    assert np.array_equal(pose12, g["pose12"]) and np.array_equal(cand, g["candidate"])
+
+
+def test_loss_golden(oracle):
+    g = np.load(os.path.join(GOLDEN, "loss_cases.npz"))
+    for o1, o2, pt, want in zip(g["obs1"], g["obs2"], g["pt"], g["loss"]):
+        got = oracle.loss(g["K"], o1, o2, pt, g["pose"])
+        assert (np.isnan(got) and np.isnan(want)) or got == want
+
+
+def numpy_two_sided(dA, pA, dB, pB, thr, gate, metric=0):
+    """matchTwoSided (match.cpp:24-94) in numpy float32: numpy does one IEEE operation per ufunc
+    call, so the running sums below are the reference's sums bit for bit."""
+    nA, nB, D = len(dA), len(dB), dA.shape[1]
+    dot = np.zeros((nA, nB), np.float32)
+    na = np.zeros((nA, 1), np.float32)
+    nb = np.zeros((1, nB), np.float32)
+    for k in range(D):
+        dot = dot + dA[:, k:k + 1] * dB[:, k:k + 1].T
+        na = na + dA[:, k:k + 1] * dA[:, k:k + 1]
+        nb = nb + (dB[:, k:k + 1] * dB[:, k:k + 1]).T
+    with np.errstate(all="ignore"):
+        sim = dot if metric else dot / (np.sqrt(na) * np.sqrt(nb))
+    dx = pA[:, None, 0] - pB[None, :, 0]
+    dy = pA[:, None, 1] - pB[None, :, 1]
+    ok = (sim > np.float32(thr)) & (dx * dx + dy * dy < np.float64(np.float32(gate)))
+    mat = np.where(ok, sim, np.float32(0))
+    m2 = np.where(mat.max(axis=0) > 0, mat.argmax(axis=0), -1)
+    m1 = np.where(mat.max(axis=1) > 0, mat.argmax(axis=1), -1)
+    pairs = [(i, m1[i]) for i in range(nA) if m1[i] != -1 and m2[m1[i]] == i]
+    return np.array(pairs, np.int32).reshape(-1, 2), m1.astype(np.int32), m2.astype(np.int32)
+
+
+@pytest.mark.parametrize("kind,thr,gate,metric", [("sift", 0.95, 1e4, 0), ("sift", 0.5, 1e8, 0), ("gauss", 0.0, 1e8, 0),
+                                                  ("gauss", 0.3, 1e8, 0), ("gauss", 5.0, 1e8, 1)])
+def test_matcher_against_numpy_restatement(oracle, kind, thr, gate, metric):
+    d, p, _ = synth.image_set(2, 160, seed=17, kind=kind)
+    dA, pA, dB, pB = d[:150], p[:150], d[160:290], p[160:290]
+    dA[4] = 0
+    dB[9] = dB[11] = dA[20]
+    got = oracle.match(dA, pA, dB, pB, threshold=thr, max_dist_sq=gate, metric=metric)
+    exp = numpy_two_sided(dA, pA, dB, pB, thr, gate, metric)
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)
+
+
+def test_similarity_is_the_reference_formula(oracle):
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal(128).astype(np.float32), rng.standard_normal(128).astype(np.float32)
+    dot = na = nb = np.float32(0)
+    for k in range(128):
+        dot = np.float32(dot + a[k] * b[k])
+        na = np.float32(na + a[k] * a[k])
+        nb = np.float32(nb + b[k] * b[k])
+    assert oracle.similarity(a, b, 0) == np.float32(dot / (np.sqrt(na) * np.sqrt(nb)))
+    assert oracle.similarity(a, b, 1) == dot
+    assert np.isnan(oracle.similarity(np.zeros(128, np.float32), b, 0))
+
+
+def test_svd3_against_lapack(oracle):
+    rng = np.random.default_rng(1)
+    for k in range(300):
+        E = rng.standard_normal((3, 3))
+        if k % 3 == 1:
+            E = rng.standard_normal((3, 2)) @ rng.standard_normal((2, 3))  # rank 2 (an essential matrix is)
+        if k % 50 == 2:
+            E = np.outer(rng.standard_normal(3), rng.standard_normal(3))   # rank 1
+        U, S, V = oracle.svd3(E)
+        assert np.allclose(U @ np.diag(S) @ V.T, E, atol=1e-12)
+        assert np.allclose(S, np.linalg.svd(E, compute_uv=False), atol=1e-12)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-9) and np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+        assert S[0] >= S[1] >= S[2] >= 0
+
+
+def test_null_vector_against_lapack(oracle):
+    rng = np.random.default_rng(2)
+    for n in (8, 8, 8, 9, 20, 200):
+        A = rng.standard_normal((n, 9))
+        q = oracle.null_vector(A)
+        v = np.linalg.svd(A)[2][-1]
+        assert min(np.abs(q - v).max(), np.abs(q + v).max()) < 1e-9
+        assert abs(np.linalg.norm(q) - 1) < 1e-12
+
+
+def test_triangulation_against_lstsq(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        a, T = rng.standard_normal(3), rng.standard_normal(3)
+        b = np.array([rng.standard_normal(), rng.standard_normal(), 1.0])
+        lam = oracle.triangulate(a, b, T)
+        ref = np.linalg.lstsq(np.stack([-a, b], axis=1), T, rcond=None)[0]
+        assert np.allclose(lam, ref, rtol=1e-8, atol=1e-10)
+
+
+def test_eight_point_recovers_noise_free_pose(oracle):
+    for seed in range(5):
+        tv = synth.two_view(40, inlier_ratio=1.0, seed=seed, noise_px=0.0)
+        pose, pts, idx, votes = oracle.eight_point_from_subset(tv["x"][:8], tv["y"][:8], tv["x"], tv["y"])
+        assert votes[idx] == 8
+        assert np.allclose(pose[:3, :3], tv["R"], atol=1e-7)
+        assert np.allclose(pose[:3, 3], tv["T"], atol=1e-7)
+        assert np.allclose(pose[3], [0, 0, 0, 1])
+        # triangulated points reproject onto both observations (depth is rounded through float: 1e-6)
+        assert np.allclose(pts[:, :2] / pts[:, 2:3], tv["x"], atol=1e-9)
+        p2 = pts @ pose[:3, :3].T + pose[:3, 3]
+        assert np.allclose(p2[:, :2] / p2[:, 2:3], tv["y"], atol=1e-5)
+        for k in range(40):
+            assert oracle.loss(tv["K"], tv["x"][k], tv["y"][k], pts[k], pose) < 1e-3
+
+
+def test_eight_point_needs_eight(oracle):
+    with pytest.raises(ValueError):
+        oracle.eight_point_from_subset(np.zeros((7, 2)), np.zeros((7, 2)), np.zeros((7, 2)), np.zeros((7, 2)))
+
+
+def test_depth_goes_through_float(oracle):
+    tv = synth.two_view(30, inlier_ratio=1.0, seed=4, noise_px=0.3)
+    _, pts, _, _ = oracle.eight_point_from_subset(tv["x"][:8], tv["y"][:8], tv["x"], tv["y"])
+    assert np.array_equal(pts[:, 2], pts[:, 2].astype(np.float32).astype(np.float64))  # eightPoint.cpp:365
+
+
+def test_loss_follows_std_max_nan_rule(oracle):
+    K = synth.default_K()
+    pose = np.eye(4)
+    # loss2 NaN only (camera-2 depth 0 -> 0/0): std::max(loss1, NaN) = loss1
+    pose[:3, 3] = [0.0, 0.0, -1.0]
+    v = oracle.loss(K, [0.0, 0.0], [0.0, 0.0], [0.0, 0.0, 1.0], pose)
+    assert v == 0.0
+    # loss1 NaN propagates
+    assert np.isnan(oracle.loss(K, [0.0, 0.0], [0.0, 0.0], [0.0, 0.0, 0.0], np.eye(4)))
+
+
+def test_ransac_against_numpy_restatement(oracle):
+    """Independent evaluation with LAPACK (svd, lstsq) of fit + triangulate + loss: counts agree
+    for hypotheses whose errors are not within rounding of the threshold (all of them here)."""
+    tv = synth.two_view(120, inlier_ratio=0.6, seed=21)
+    x, y, K = tv["x"], tv["y"], tv["K"]
+    S = synth.sample_table(120, 40, seed=22)
+    r = oracle.ransac(x, y, K, S, max_sq_err=1.0, adaptive=False)
+    xh = np.concatenate([x, np.ones((120, 1))], axis=1)
+    yh = np.concatenate([y, np.ones((120, 1))], axis=1)
+    pose12, _ = oracle.fit_hypotheses(x, y, S)
+    for h in range(40):
+        A = np.stack([np.kron(yh[i], xh[i]) for i in S[h]])
+        E = np.linalg.svd(A)[2][-1].reshape(3, 3)
+        R, T = pose12[h, :9].reshape(3, 3), pose12[h, 9:]
+        Tx = np.array([[0, -T[2], T[1]], [T[2], 0, -T[0]], [-T[1], T[0], 0]])
+        E2 = Tx @ R
+        # the restatement's (R, T) factorises the LAPACK null vector up to scale and the rank-2 projection
+        Ue, Se, Vte = np.linalg.svd(E)
+        Eproj = Ue @ np.diag([1, 1, 0]) @ Vte
+        c = (E2 * Eproj).sum() / (Eproj * Eproj).sum()
+        assert np.allclose(E2, c * Eproj, atol=1e-6)
+        cnt = 0
+        for k in range(120):
+            lam = np.linalg.lstsq(np.stack([-(R @ xh[k]), yh[k]], axis=1), T, rcond=None)[0]
+            P = np.float64(np.float32(lam[0])) * xh[k]
+            e1 = np.sum(((K @ P)[:2] / (K @ P)[2] - (K @ xh[k])[:2]) ** 2)
+            q = K @ (R @ P + T)
+            e2 = np.sum((q[:2] / q[2] - (K @ yh[k])[:2]) ** 2)
+            cnt += max(e1, e2) < 1.0
+        assert cnt == r["counts"][h]
+
+
+def test_adaptive_cap_formula(oracle):
+    import math
+    for c, n, p in [(60, 100, 0.99), (1500, 3000, 0.999), (20, 100, 0.99), (100, 100, 0.99), (17, 100, 0.999)]:
+        sp = (c / n) ** 8
+        want = -1 if sp < 1e-6 else (0 if sp >= 1.0 and False else None)
+        got = oracle.adaptive_max_iter(c, n, 8, p)
+        if sp < 1e-6:
+            assert got == -1                      # RANSAC.cpp:248: cap not applied
+        elif sp >= 1.0:
+            assert got == 0                       # log(0) = -inf -> ceil(-0.0) -> 0
+        else:
+            assert got == math.ceil(math.log(1 - p) / math.log(1 - sp))
+
+
+def test_ransac_guards(oracle):
+    tv = synth.two_view(7, inlier_ratio=1.0, seed=1)
+    r = oracle.ransac(tv["x"], tv["y"], tv["K"], np.zeros((4, 8), np.int32))
+    assert len(r["inliers"]) == 0 and r["best_h"] == -1   # RANSAC.cpp:148-149
+    r = oracle.ransac(tv["x"], tv["y"][:3], tv["K"], np.zeros((4, 8), np.int32))
+    assert len(r["inliers"]) == 0
+
+
+def test_ransac_in_order_adaptive_scan(oracle):
+    tv = synth.two_view(400, inlier_ratio=0.8, seed=31, noise_px=0.02)
+    S = synth.sample_table(400, 300, seed=32)
+    full = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=2.0, success_prob=0.99, adaptive=False)
+    ad = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=2.0, success_prob=0.99, adaptive=True)
+    assert full["iterations"] == 300 and ad["iterations"] < 300
+    # replay the scan in Python
+    best, bc, be, max_iter, done = -1, 0, np.inf, 300, 0
+    for h in range(300):
+        if done >= max_iter:
+            break
+        done += 1
+        c, e = full["counts"][h], full["toterr"][h]
+        if c > 0 and (c > bc or (c == bc and e < be)):
+            best, bc, be = h, c, e
+            m = oracle.adaptive_max_iter(int(c), 400, 8, 0.99)
+            if 0 <= m < max_iter:
+                max_iter = m
+    assert (ad["best_h"], ad["iterations"]) == (best, done)
+    assert len(ad["inliers"]) == bc
+
+
+def test_normalize_points(oracle):
+    K = synth.default_K()
+    px = np.array([[2000.0, 1500.0], [0.0, 0.0], [3999.0, 17.5]])
+    got = oracle.normalize_points(K, px)
+    assert np.allclose(got, (px - [2000, 1500]) / 3000.0, atol=1e-15)
