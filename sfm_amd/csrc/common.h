@@ -18,6 +18,7 @@ struct sfm_ctx {
     int64_t cand_capacity = 32768;   // candidate slots per image pair
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
     int64_t hyps_per_launch = 0;     // 0 = all hypotheses of a RANSAC call in one launch
+    int sim_variant = 4;             // index into the similarity kernel's instance table
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };
     std::vector<Span> span_pool[2]; // events are created once and reused
@@ -106,5 +107,6 @@ struct PinBuf {
 hipError_t sfm_span_begin(sfm_ctx *ctx, int which);
 hipError_t sfm_span_end(sfm_ctx *ctx, int which);
 void sfm_span_reset(sfm_ctx *ctx, int which);
+int sfm_num_sim_variants();
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

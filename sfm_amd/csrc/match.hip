@@ -32,8 +32,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
 #define KDIM 128         // padded descriptor length of the fp16 table
-#define ROW_PAD 512      // every image's fp16 rows are padded to a multiple of this
-#define BN 128           // B descriptors staged in LDS per step
+#define ROW_PAD 1024     // every image's fp16 rows are padded to a multiple of this
 #define SIM_MARGIN 1.5e-3f
 
 // flags per image
@@ -57,10 +56,16 @@ struct MatchArgs {
     const PairRec *pairs; // chunk base
     const int2 *work;     // (pair in chunk, row block), -1 = no work
     uint2 *cand;          // [pairs in chunk][candCap]
-    int *candCount;       // [pairs in chunk]
+    int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
+    int *pairOvf;         // [pairs in chunk]: 1 = a slice overflowed, score the pair cell by cell
+    int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
     u64 *best;            // row keys and column keys of the chunk
-    u64 *stats;           // [0] candidates scored from lists, [1] overflow cells
+    unsigned *runMax;     // running lower bounds of each row's / column's best similarity (ordered keys)
+    int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
+    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell
     int candCap;
+    int blockRows;        // rows of image A per block of the similarity kernel instance in use
+    int wavesPerBlock;
     int dim;
     int metric;
     float threshold;
@@ -157,46 +162,185 @@ __device__ __forceinline__ void fold_cell(const MatchArgs &g, const PairRec &pr,
     atomicMax(&g.best[pr.bestCol + j], bits | (u64)(0xFFFFFFFFu - (unsigned)i));
 }
 
-// Out-of-line so that the similarity kernel's register budget is set by its main loop.
-__device__ __noinline__ void fold_cell_overflow(const MatchArgs *g, int pairInChunk, int i, int j)
+// Monotone map float -> unsigned (larger float, larger key); key 0 is below every float.
+__device__ __forceinline__ unsigned ordered_key(float v)
 {
-    const PairRec pr = g->pairs[pairInChunk];
-    fold_cell(*g, pr, i, j);
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-__device__ __forceinline__ void emit_candidate(const MatchArgs &g, const PairRec &pr, int i, int j)
+// A zero the optimiser cannot see through.  Index arithmetic of the rare candidate path is
+// made to depend on it so that none of it is hoisted into the main loop's register budget.
+__device__ __forceinline__ int opaque_zero()
 {
-    const int slot = atomicAdd(&g.candCount[pr.chunkLocal], 1);
-    if (slot < g.candCap) {
-        g.cand[(size_t)pr.chunkLocal * g.candCap + slot] = make_uint2((unsigned)i, (unsigned)j);
-    } else {
-        fold_cell_overflow(&g, pr.chunkLocal, i, j);
-    }
+    int z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+#endif
+    return z;
 }
 
 // ---------------------------------------------------------------------------------------
 // similarity kernel
 // ---------------------------------------------------------------------------------------
 // Block = WAVES waves.  Wave w keeps RT*32 rows of image A as MFMA A-operand fragments in
-// registers for the whole block; image B streams through LDS, BN descriptors per step,
+// registers for the whole block; image B streams through LDS, BN_ descriptors per step,
 // double buffered, one barrier per step.  LDS rows are 256 B (128 fp16); 16-byte chunk c of
 // row r is stored at chunk c ^ (r & 15), which makes the ds_read_b128 fragment reads
 // (32 rows, same logical chunk) conflict-free.
 //
 // MFMA operand map (32x32x16, f16): lane l, r = l & 31, h = l >> 5 holds A[row r][k = 8h..8h+7]
 // and B[k = 8h..8h+7][col r]; result register q of lane l is C[(q&3) + 8*(q>>2) + 4*h][r].
-template <int RT, int WAVES, bool DOT>
-__global__ __launch_bounds__(WAVES * 64) void match_sim_kernel(const MatchArgs g)
+
+// Candidates leave the kernel through per-wave queues in global memory: every wave of every
+// block owns a fixed slice of its pair's candidate list and appends with plain stores at a
+// wave-uniform cursor, so the hot kernel has no atomics with return values and never waits on
+// memory in the candidate path.  A slice that fills up flags the pair for cell-by-cell scoring.
+struct WaveQueue {
+    uint2 *base;
+    int cap;
+    int n; // wave-uniform cursor (may run past cap: then the pair is flagged)
+};
+
+__device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int j, int lane)
 {
-    constexpr int NT = WAVES * 64;
-    constexpr int PIECES = BN * 16 / NT; // 16-byte pieces of one B step per thread
-    static_assert(BN * 16 % NT == 0, "staging must divide evenly");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BN * 256];
+    const u64 em = __builtin_amdgcn_ballot_w64(take);
+    if (em == 0) return;
+    const int slot = wq.n + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+    if (take && slot < wq.cap) wq.base[slot] = make_uint2((unsigned)i, (unsigned)j);
+    wq.n += __builtin_popcountll(em);
+}
+
+// Candidate test of one 32-column accumulator tile set (RT tiles of 32 rows) and the rare
+// emission path.  j = this lane's column.
+//
+// Normal mode: every cell above the bound is queued.  Once a wave has queued half its slice
+// (loose thresholds, where most cells clear the bound), and always for the dot metric, a cell is
+// queued only if it can still be the best of its row or of its column: its upper bound must reach
+// the largest lower bound seen so far there (runMax, ordered keys, 0 = nothing yet).  The true
+// arg-max always passes: its upper bound is at least its exact value, which is at least every
+// other cell's exact value, which is at least that cell's lower bound.  Racing updates only make
+// the test more permissive.
+template <int RT, bool DOT>
+__device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const float16v (&acc)[RT],
+                                             int rowBase, int j, int lane, float thr_m, WaveQueue &wq)
+{
+    bool hit = DOT;
+    if (!DOT) {
+        // fmaxf ignores NaNs, and a NaN cell can never be accepted.  Four independent chains keep
+        // the dependent-issue latency short; no branch, so the chain can be scheduled among MFMAs.
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const int k = ((t * 16 + q) >> 1) & 3;
+                m[k] = fmaxf(fmaxf(m[k], acc[t][q]), acc[t][q + 1]);
+            }
+        hit = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) > thr_m;
+    }
+    if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+
+    // rare path
+    const int z = opaque_zero();
+    const int jj = j + z;
+    const int h = (lane >> 5) + z;
+    const bool colValid = jj < pr.nB;
+    if (!(thr_m > -INFINITY)) { // norms out of range: no bound holds, score the pair cell by cell
+        wq.n = wq.cap + 1;
+        return;
+    }
+
+    if (!DOT && wq.n * 2 < wq.cap) {
+        u64 bits = 0;
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) bits |= (u64)(acc[t][q] > thr_m) << (t * 16 + q);
+        if (!colValid) bits = 0;
+        while (__builtin_amdgcn_ballot_w64(bits != 0) != 0) {
+            const bool has = bits != 0;
+            const int bit = has ? __builtin_ctzll(bits) : 0;
+            bits &= bits - 1;
+            const int q = bit & 15;
+            const int i = rowBase + (bit >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            queue_push(wq, has && i < pr.nA, i, jj, lane);
+        }
+        return;
+    }
+
+    const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
+    const float thrp = fmaxf(g.threshold, 0.0f);
+    unsigned *colSlot = g.runMax + pr.bestCol + (colValid ? jj : 0);
+    const unsigned colKey0 = colValid ? *colSlot : 0u;
+    unsigned colKey = colKey0;
+#pragma unroll
+    for (int t = 0; t < RT; t++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float v = acc[t][q];
+            const int i = rowBase + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            bool take = false;
+            if (colValid && i < pr.nA && (DOT || v > thr_m)) {
+                float lo = v - SIM_MARGIN, hi = v + SIM_MARGIN;
+                bool cnd = true;
+                if (DOT) { // dot = approx * sA * sB within 1e-3 * sA * sB
+                    const float p = g.norms[pr.rowA32 + i] * sB;
+                    lo *= p;
+                    hi *= p;
+                    cnd = hi > thrp;
+                }
+                if (cnd) {
+                    unsigned *rowSlot = g.runMax + pr.bestRow + i;
+                    const unsigned rowKey = *rowSlot;
+                    const bool rowOk = rowKey == 0 || hi >= ordered_value(rowKey);
+                    const bool colOk = colKey == 0 || hi >= ordered_value(colKey);
+                    if (rowOk || colOk) {
+                        const unsigned klo = ordered_key(lo);
+                        if (klo > rowKey) atomicMax(rowSlot, klo);
+                        colKey = max(colKey, klo);
+                        take = true;
+                    }
+                }
+            }
+            queue_push(wq, take, i, jj, lane);
+        }
+    if (colKey > colKey0) atomicMax(colSlot, colKey);
+}
+
+template <int RT> __device__ __forceinline__ void keep_alive(const float16v (&acc)[RT])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int t = 0; t < RT; t++) asm volatile("" ::"v"(acc[t]));
+#endif
+}
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// Image B reaches LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, written
+// linearly at a wave-uniform base), so the XOR swizzle is applied to the per-lane source address.
+// PIPE = 1: two accumulator sets; the candidate test of one 32-column step is issued among the
+// MFMAs of the next one.
+// ABL: timing-only ablations (wrong results): 1 = no staging and no barrier, 2 = no candidate test.
+template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL>
+__global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
+{
+    constexpr int NSUB = BN_ / 32;
+    constexpr int DMA = BN_ * 256 / 1024 / WAVES; // LDS-DMA instructions per wave per step
+    static_assert(BN_ * 256 % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BN_ * 256];
 
     const int2 w = g.work[blockIdx.x];
     if (w.x < 0) return;
     const PairRec pr = g.pairs[w.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int rowBase = w.y * (WAVES * RT * 32) + wave * (RT * 32);
 
@@ -210,126 +354,167 @@ __global__ __launch_bounds__(WAVES * 64) void match_sim_kernel(const MatchArgs g
         for (int s = 0; s < 8; s++)
             a[t][s] = *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
 
-    const int nChunks = (pr.nB + BN - 1) / BN;
+    const int nChunks = (pr.nB + BN_ - 1) / BN_;
     // the bound is the same for the whole block: keep it (and the branch on it) scalar
-    const int thrBits = __builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m));
-    const float thr_m = __int_as_float(thrBits);
-    const bool posThr = thr_m >= 0.0f;
+    const float thr_m = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m)));
 
-    uint4 stage[PIECES];
-    auto stage_load = [&](int c) {
+    // LDS-DMA: instruction u of this wave fills 1 KiB = rows 4*blk .. 4*blk+3 of the step; lane l
+    // lands at row 4*blk + (l >> 4), physical chunk l & 15, which holds logical chunk (l & 15) ^ (row & 15).
+    unsigned srcOff[DMA];
 #pragma unroll
-        for (int u = 0; u < PIECES; u++) {
-            const int q = tid + NT * u;
-            stage[u] = *reinterpret_cast<const uint4 *>(B16 + ((size_t)c * BN + (q >> 4)) * 256 + (q & 15) * 16);
+    for (int u = 0; u < DMA; u++) {
+        const int row = 4 * (wave * DMA + u) + (lane >> 4);
+        srcOff[u] = row * 256 + (((lane & 15) ^ (row & 15)) << 4);
+    }
+    auto dma_issue = [&](int c, int buf) {
+        const unsigned char *src = B16 + (size_t)c * BN_ * 256;
+#pragma unroll
+        for (int u = 0; u < DMA; u++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + srcOff[u]), (lptr_t)&lds[buf][(wave * DMA + u) * 1024], 16, 0, 0);
+    };
+    auto mfma_step = [&](float16v (&acc)[RT], int buf, int sub) {
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[t][q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const half8 b = *reinterpret_cast<const half8 *>(&lds[buf][(sub * 32 + r) * 256 + (((2 * s + h) ^ (r & 15)) << 4)]);
+#pragma unroll
+            for (int t = 0; t < RT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][s], b, acc[t], 0, 0, 0);
         }
     };
-    auto stage_store = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PIECES; u++) {
-            const int q = tid + NT * u;
-            const int row = q >> 4, ch = q & 15;
-            *reinterpret_cast<uint4 *>(&lds[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[u];
-        }
+    // this wave's slice of the pair's candidate list
+    const int nQueues = ((pr.nA + WAVES * RT * 32 - 1) / (WAVES * RT * 32)) * WAVES;
+    const int queueId = w.y * WAVES + wave;
+    WaveQueue wq;
+    wq.cap = g.candCap / nQueues;
+    wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
+    wq.n = 0;
+    auto test = [&](const float16v (&acc)[RT], int j) {
+        if constexpr ((ABL & 2) != 0)
+            keep_alive<RT>(acc);
+        else
+            sim_epilogue<RT, DOT>(g, pr, acc, rowBase, j, lane, thr_m, wq);
     };
 
-    stage_load(0);
-    stage_store(0);
+    dma_issue(0, 0);
     __syncthreads();
 
+    float16v accA[RT], accB[RT];
+    int jPrev = 0x40000000; // "no previous step": beyond every column
+    if (PIPE) {
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) accB[t][q] = 0.0f;
+    }
+
     for (int c = 0; c < nChunks; c++) {
-        const int buf = c & 1;
-        if (c + 1 < nChunks) stage_load(c + 1);
-
+        const int buf = (ABL & 1) ? 0 : (c & 1);
+        if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
 #pragma unroll
-        for (int sub = 0; sub < BN / 32; sub++) {
-            float16v acc[RT];
-#pragma unroll
-            for (int t = 0; t < RT; t++)
-#pragma unroll
-                for (int q = 0; q < 16; q++) acc[t][q] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const half8 b = *reinterpret_cast<const half8 *>(
-                    &lds[buf][(sub * 32 + r) * 256 + (((2 * s + h) ^ (r & 15)) << 4)]);
-#pragma unroll
-                for (int t = 0; t < RT; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][s], b, acc[t], 0, 0, 0);
-            }
-
-            bool hit = false;
-            if (DOT) {
-                hit = true;
-            } else if (posThr) {
-                // non-negative bound: float order == signed-int order of the bit patterns
-                int m = (int)0x80000000;
-#pragma unroll
-                for (int t = 0; t < RT; t++)
-#pragma unroll
-                    for (int q = 0; q < 16; q++) m = max(m, __float_as_int(acc[t][q]));
-                hit = m > thrBits;
+        for (int sub = 0; sub < NSUB; sub += 2) {
+            const int j0 = c * BN_ + sub * 32 + r;
+            if (PIPE) {
+                mfma_step(accA, buf, sub);
+                test(accB, jPrev);
+                mfma_step(accB, buf, sub + 1);
+                test(accA, j0);
+                jPrev = j0 + 32;
             } else {
-#pragma unroll
-                for (int t = 0; t < RT; t++)
-#pragma unroll
-                    for (int q = 0; q < 16; q++) hit |= acc[t][q] > thr_m;
-            }
-            if (__builtin_amdgcn_ballot_w64(hit) != 0) {
-                // rare path: one bit per accumulator register that is a candidate
-                const int j = c * BN + sub * 32 + r;
-                u64 mask = 0;
-                if (DOT) {
-                    // dot = approx * sA * sB within 1e-3 * sA * sB
-                    const float thrp = fmaxf(g.threshold, 0.0f);
-                    const float invB = (j < pr.nB) ? thrp / g.norms[pr.rowB32 + j] : 0.0f;
-#pragma unroll
-                    for (int t = 0; t < RT; t++)
-#pragma unroll
-                        for (int q = 0; q < 16; q++) {
-                            const int i = rowBase + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                            const float invA = (i < pr.nA) ? 1.0f / g.norms[pr.rowA32 + i] : 0.0f;
-                            const bool cnd = (acc[t][q] - invA * invB) > -SIM_MARGIN || !(thr_m > -INFINITY);
-                            mask |= (u64)cnd << (t * 16 + q);
-                        }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < RT; t++)
-#pragma unroll
-                        for (int q = 0; q < 16; q++) mask |= (u64)(acc[t][q] > thr_m) << (t * 16 + q);
-                }
-                if (j >= pr.nB) mask = 0;
-                while (mask) {
-                    const int bit = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const int q = bit & 15;
-                    const int i = rowBase + (bit >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                    if (i < pr.nA) emit_candidate(g, pr, i, j);
-                }
+                mfma_step(accA, buf, sub);
+                test(accA, j0);
+                mfma_step(accA, buf, sub + 1);
+                test(accA, j0 + 32);
             }
         }
-
-        if (c + 1 < nChunks) stage_store(buf ^ 1);
-        __syncthreads();
+        if (!(ABL & 1)) __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
+    }
+    if (PIPE) test(accB, jPrev);
+    if (lane == 0) {
+        g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
+        if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = 1;
     }
 }
+
+// The instances that can be selected with sfm_ctx_set_option("sim_variant").
+struct SimVariant {
+    int blockRows, threads;
+    void (*cos)(const MatchArgs);
+    void (*dot)(const MatchArgs);
+    const char *name;
+};
+#define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL)                                                        \
+    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL>,                \
+     match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, true, ABL>,                                               \
+     "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL}
+static const SimVariant kSimVariants[] = {
+    SIM_VARIANT(2, 8, 128, 2, 0, 0), // 0: 8 waves x 64 rows, one block per CU
+    SIM_VARIANT(2, 8, 128, 4, 0, 0), // 1: same, two blocks per CU (<= 128 VGPRs)
+    SIM_VARIANT(2, 8, 128, 2, 1, 0), // 2: pipelined candidate test
+    SIM_VARIANT(4, 8, 128, 2, 0, 0), // 3: 8 waves x 128 rows
+    SIM_VARIANT(2, 4, 64, 3, 0, 0),  // 4: 4 waves x 64 rows, three blocks per CU
+    SIM_VARIANT(2, 4, 64, 4, 0, 0),  // 5
+    SIM_VARIANT(2, 8, 256, 2, 0, 0), // 6
+    SIM_VARIANT(2, 4, 128, 2, 0, 0), // 7
+    SIM_VARIANT(2, 8, 128, 2, 0, 1), // 8: ablation, no staging
+    SIM_VARIANT(2, 8, 128, 2, 0, 2), // 9: ablation, no candidate test
+    SIM_VARIANT(2, 8, 128, 2, 0, 3), // 10: ablation, neither
+};
+static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
 // ---------------------------------------------------------------------------------------
 // exact pass over the candidate lists
 // ---------------------------------------------------------------------------------------
+// One wave per candidate slice, four slices per block.
 __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
 {
     const int p = blockIdx.y;
+    if (g.pairOvf[p]) return; // match_exact_kernel scores the whole pair
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= g.maxQueues) return;
     const PairRec pr = g.pairs[p];
-    int n = g.candCount[p];
-    if (n > g.candCap) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.stats[1], (u64)(n - g.candCap));
-        n = g.candCap;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g.stats[0], (u64)n);
-    const uint2 *list = g.cand + (size_t)p * g.candCap;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const int nQueues = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
+    if (q >= nQueues) return;
+    const int cap = g.candCap / nQueues;
+    const int n = g.candCount[p * g.maxQueues + q];
+    if (n > 0 && lane == 0) atomicAdd(&g.stats[0], (u64)n);
+    const uint2 *list = g.cand + (size_t)p * g.candCap + (size_t)q * cap;
+    for (int k = lane; k < n; k += 64) {
         const uint2 c = list[k];
         fold_cell(g, pr, (int)c.x, (int)c.y);
+    }
+}
+
+// Pairs whose candidate list overflowed (one block): ovfList[0] = count, then the pair indices.
+__global__ __launch_bounds__(256) void match_overflow_list_kernel(const MatchArgs g, int nPairs)
+{
+    __shared__ int n;
+    if (threadIdx.x == 0) n = 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < nPairs; p += blockDim.x)
+        if (g.pairOvf[p]) g.ovfList[1 + atomicAdd(&n, 1)] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        g.ovfList[0] = n;
+        if (n) atomicAdd(&g.stats[1], (u64)n);
+    }
+}
+
+// Every cell of every overflowed pair, scored exactly.  Slow (a dependent 128-step chain per
+// cell) but only reached when more cells than the list holds can still be a row or column best,
+// e.g. many identical descriptors.  Consecutive threads take consecutive columns of one row.
+__global__ __launch_bounds__(256) void match_exact_kernel(const MatchArgs g)
+{
+    const int n = g.ovfList[0];
+    for (int k = 0; k < n; k++) {
+        const PairRec pr = g.pairs[g.ovfList[1 + k]];
+        const long long cells = (long long)pr.nA * pr.nB;
+        for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cells;
+             c += (long long)gridDim.x * blockDim.x)
+            fold_cell(g, pr, (int)(c / pr.nB), (int)(c % pr.nB));
     }
 }
 
@@ -434,7 +619,7 @@ struct sfm_match_result {
     int n_pairs = 0;
     DevBuf offsets; // int64[n_pairs+1]
     DevBuf pairs;   // int2[sum min(nA,nB)]
-    DevBuf pairRecs, work, cand, candCount, best, counts, stats, m1, m2;
+    DevBuf pairRecs, work, cand, candCount, pairOvf, best, runMax, ovfList, counts, stats, m1, m2;
     PinBuf hostRecs, hostWork;
     int64_t total = -1;
 };
@@ -565,19 +750,15 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
-    DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount,
-                      &r->best, &r->counts, &r->stats, &r->m1, &r->m2};
+    DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
+                      &r->best, &r->runMax, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2};
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
     delete r;
 }
 
-// shape of the similarity kernel instance in use
-static const int RT_USED = 2;
-static const int WAVES_USED = 8;
-static const int BLOCK_ROWS = WAVES_USED * RT_USED * 32;
-static_assert(BLOCK_ROWS <= ROW_PAD && ROW_PAD % BN == 0, "fp16 row padding must cover a block");
+int sfm_num_sim_variants() { return kNumSimVariants; }
 
 static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
                             int metric, float threshold, float maxDistSq, sfm_match_result **result_inout,
@@ -603,6 +784,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     res->total = -1;
     sfm_span_reset(ctx, 0);
 
+    const SimVariant &variant = kSimVariants[ctx->sim_variant];
+    const int BLOCK_ROWS = variant.blockRows; // <= ROW_PAD
     const int chunkPairs = (int)std::min<int64_t>(ctx->pairs_per_launch, n_pairs > 0 ? n_pairs : 1);
     const int candCap = (int)ctx->cand_capacity;
 
@@ -614,6 +797,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     std::vector<int> chunkWorkCount;
     int64_t workTotal = 0;
     int maxNA = 0, maxNB = 0;
+    const int wavesPerBlock = variant.threads / 64;
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
         int64_t bestOff = 0;
@@ -684,8 +868,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, res->pairs.reserve((size_t)(outTotalCap ? outTotalCap : 1) * sizeof(int2)));
     SFM_HIP(ctx, res->cand.reserve((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)));
-    SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * sizeof(int)));
+    const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
+    SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * maxQueues * sizeof(int)));
+    SFM_HIP(ctx, res->pairOvf.reserve((size_t)chunkPairs * sizeof(int)));
     SFM_HIP(ctx, res->best.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(u64)));
+    SFM_HIP(ctx, res->runMax.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(unsigned)));
+    SFM_HIP(ctx, res->ovfList.reserve((size_t)(chunkPairs + 1) * sizeof(int)));
     SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
     SFM_HIP(ctx, res->stats.reserve(2 * sizeof(u64)));
     if (want_m1m2) {
@@ -707,7 +895,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.pts = set->pts.as<double2>();
     g.cand = res->cand.as<uint2>();
     g.candCount = res->candCount.as<int>();
+    g.pairOvf = res->pairOvf.as<int>();
+    g.maxQueues = maxQueues;
+    g.blockRows = BLOCK_ROWS;
+    g.wavesPerBlock = wavesPerBlock;
     g.best = res->best.as<u64>();
+    g.runMax = res->runMax.as<unsigned>();
+    g.ovfList = res->ovfList.as<int>();
     g.stats = res->stats.as<u64>();
     g.candCap = candCap;
     g.dim = set->dim;
@@ -722,21 +916,22 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         g.pairs = res->pairRecs.as<PairRec>() + c0;
         g.work = res->work.as<int2>() + chunkWorkBase[ci];
         int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
-        if (bestLen > 0) SFM_HIP(ctx, hipMemsetAsync(res->best.p, 0, (size_t)bestLen * sizeof(u64), st));
-        SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * sizeof(int), st));
+        if (bestLen > 0) {
+            SFM_HIP(ctx, hipMemsetAsync(res->best.p, 0, (size_t)bestLen * sizeof(u64), st));
+            SFM_HIP(ctx, hipMemsetAsync(res->runMax.p, 0, (size_t)bestLen * sizeof(unsigned), st));
+        }
+        SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * maxQueues * sizeof(int), st));
+        SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)np * sizeof(int), st));
         const int nblk = chunkWorkCount[ci];
         if (nblk > 0) {
             SFM_HIP(ctx, sfm_span_begin(ctx, 0));
-            if (metric == SFM_METRIC_COSINE)
-                hipLaunchKernelGGL((match_sim_kernel<RT_USED, WAVES_USED, false>), dim3(nblk), dim3(WAVES_USED * 64), 0, st, g);
-            else
-                hipLaunchKernelGGL((match_sim_kernel<RT_USED, WAVES_USED, true>), dim3(nblk), dim3(WAVES_USED * 64), 0, st, g);
+            hipLaunchKernelGGL(metric == SFM_METRIC_COSINE ? variant.cos : variant.dot, dim3(nblk),
+                               dim3(variant.threads), 0, st, g);
             SFM_HIP(ctx, sfm_span_end(ctx, 0));
-            if (candCap > 0) {
-                int cb = (candCap + 255) / 256;
-                if (cb > 16) cb = 16;
-                hipLaunchKernelGGL(match_cand_kernel, dim3(cb, np), dim3(256), 0, st, g);
-            }
+            if (candCap > 0)
+                hipLaunchKernelGGL(match_cand_kernel, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
+            hipLaunchKernelGGL(match_overflow_list_kernel, dim3(1), dim3(256), 0, st, g, np);
+            hipLaunchKernelGGL(match_exact_kernel, dim3(4 * ctx->n_cus), dim3(256), 0, st, g);
         }
         hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
                            res->counts.as<int>(), (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr,
