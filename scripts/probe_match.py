@@ -29,7 +29,7 @@ for rd in range(rounds + 1):
         tot = res.total()
         if ref_total is None:
             ref_total = tot
-        assert tot == ref_total or v >= 8, (v, tot, ref_total)
+        assert tot == ref_total or v >= 9, (v, tot, ref_total)
         if rd > 0:
             b = best.setdefault(v, [1e9, 1e9, []])
             b[0] = min(b[0], ms); b[1] = min(b[1], dt * 1e3); b[2].append(ms)

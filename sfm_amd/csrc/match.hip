@@ -24,6 +24,8 @@
 // reference's for any finite input, not only for integer-valued SIFT descriptors.
 #include "common.h"
 
+#include <type_traits>
+
 // Every fp32/fp64 operation of the exact pass must be the one written: no fused multiply-adds.
 #pragma clang fp contract(off)
 
@@ -130,6 +132,24 @@ __global__ void ingest_f16_kernel(const float *__restrict__ desc32, const ImageR
 // ---------------------------------------------------------------------------------------
 // exact evaluation of one cell, as the reference computes it
 // ---------------------------------------------------------------------------------------
+// The part of a cell's evaluation after the dot product: metric, threshold, pixel gate, arg-max keys.
+__device__ __forceinline__ void fold_dot(const MatchArgs &g, const PairRec &pr, int i, int j, float dot)
+{
+    float sim = dot; // match.hpp:18-27
+    if (g.metric == SFM_METRIC_COSINE) // match.hpp:45
+        sim = __fdiv_rn(dot, __fmul_rn(g.norms[pr.rowA32 + i], g.norms[pr.rowB32 + j]));
+    if (!(sim > g.threshold)) return; // match.cpp:45
+    const double2 pa = g.pts[pr.rowA32 + i], pb = g.pts[pr.rowB32 + j];
+    const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
+    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+    if (!(d2 < (double)g.maxDistSq)) return;
+    if (!(sim > 0.0f)) return; // match.cpp:38,49 / :68,72: must beat maxSimilarity = 0
+    // max sim first, then lowest index: the strict '>' scans of match.cpp:49 and :72.
+    const u64 bits = (u64)__float_as_uint(sim) << 32;
+    atomicMax(&g.best[pr.bestRow + i], bits | (u64)(0xFFFFFFFFu - (unsigned)j));
+    atomicMax(&g.best[pr.bestCol + j], bits | (u64)(0xFFFFFFFFu - (unsigned)i));
+}
+
 __device__ __forceinline__ void fold_cell(const MatchArgs &g, const PairRec &pr, int i, int j)
 {
     const float *a = g.desc32 + (size_t)(pr.rowA32 + i) * g.dim;
@@ -147,19 +167,7 @@ __device__ __forceinline__ void fold_cell(const MatchArgs &g, const PairRec &pr,
     } else {
         for (int k = 0; k < g.dim; k++) dot = __fadd_rn(dot, __fmul_rn(a[k], b[k]));
     }
-    float sim = dot; // match.hpp:18-27
-    if (g.metric == SFM_METRIC_COSINE) // match.hpp:45
-        sim = __fdiv_rn(dot, __fmul_rn(g.norms[pr.rowA32 + i], g.norms[pr.rowB32 + j]));
-    if (!(sim > g.threshold)) return; // match.cpp:45
-    const double2 pa = g.pts[pr.rowA32 + i], pb = g.pts[pr.rowB32 + j];
-    const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
-    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
-    if (!(d2 < (double)g.maxDistSq)) return;
-    if (!(sim > 0.0f)) return; // match.cpp:38,49 / :68,72: must beat maxSimilarity = 0
-    // max sim first, then lowest index: the strict '>' scans of match.cpp:49 and :72.
-    const u64 bits = (u64)__float_as_uint(sim) << 32;
-    atomicMax(&g.best[pr.bestRow + i], bits | (u64)(0xFFFFFFFFu - (unsigned)j));
-    atomicMax(&g.best[pr.bestCol + j], bits | (u64)(0xFFFFFFFFu - (unsigned)i));
+    fold_dot(g, pr, i, j, dot);
 }
 
 // Monotone map float -> unsigned (larger float, larger key); key 0 is below every float.
@@ -215,8 +223,54 @@ __device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int 
     wq.n += __builtin_popcountll(em);
 }
 
-// Candidate test of one 32-column accumulator tile set (RT tiles of 32 rows) and the rare
-// emission path.  j = this lane's column.
+// Accumulators of one 32-column step of a wave (RT*32 rows), for the two MFMA shapes.
+// A lane's values are numbered idx = 0..NV-1 in NGROUP groups that share a column.
+//   32x32x16: lane l holds column l & 31; register q of row tile t is row 32t + (q&3) + 8(q>>2) + 4(l>>5).
+//   16x16x32: lane l holds columns (l & 15) and 16 + (l & 15); register q of row tile t is row
+//             16t + 4(l>>4) + q.
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int RT> struct Acc32 {
+    static constexpr int NV = RT * 16, NGROUP = 1, GROUP = NV;
+    float16v a[RT];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int t = 0; t < RT; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) a[t][q] = 0.0f;
+    }
+    __device__ __forceinline__ float get(int idx) const { return a[idx >> 4][idx & 15]; }
+    __device__ static __forceinline__ int row(int idx, int lane)
+    {
+        const int q = idx & 15;
+        return (idx >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    }
+    __device__ static __forceinline__ int col(int, int lane) { return lane & 31; }
+};
+
+template <int RT> struct Acc16 {
+    static constexpr int RT16 = RT * 2, NV = 2 * RT16 * 4, NGROUP = 2, GROUP = RT16 * 4;
+    float4v a[2][RT16];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int t = 0; t < RT16; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[c][t][q] = 0.0f;
+    }
+    __device__ __forceinline__ float get(int idx) const { return a[idx / GROUP][(idx % GROUP) >> 2][idx & 3]; }
+    __device__ static __forceinline__ int row(int idx, int lane)
+    {
+        return ((idx % GROUP) >> 2) * 16 + 4 * (lane >> 4) + (idx & 3);
+    }
+    __device__ static __forceinline__ int col(int idx, int lane) { return (idx / GROUP) * 16 + (lane & 15); }
+};
+
+// Candidate test of one 32-column step and the rare emission path.  colBase = first column of
+// the step.
 //
 // Normal mode: every cell above the bound is queued.  Once a wave has queued half its slice
 // (loose thresholds, where most cells clear the bound), and always for the dot metric, a cell is
@@ -225,31 +279,25 @@ __device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int 
 // arg-max always passes: its upper bound is at least its exact value, which is at least every
 // other cell's exact value, which is at least that cell's lower bound.  Racing updates only make
 // the test more permissive.
-template <int RT, bool DOT>
-__device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const float16v (&acc)[RT],
-                                             int rowBase, int j, int lane, float thr_m, WaveQueue &wq)
+template <typename AccT, bool DOT>
+__device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
+                                             int colBase, int lane, float thr_m, WaveQueue &wq)
 {
+    constexpr int NV = AccT::NV;
     bool hit = DOT;
     if (!DOT) {
         // fmaxf ignores NaNs, and a NaN cell can never be accepted.  Four independent chains keep
         // the dependent-issue latency short; no branch, so the chain can be scheduled among MFMAs.
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int t = 0; t < RT; t++)
-#pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const int k = ((t * 16 + q) >> 1) & 3;
-                m[k] = fmaxf(fmaxf(m[k], acc[t][q]), acc[t][q + 1]);
-            }
+        for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = fmaxf(fmaxf(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
         hit = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) > thr_m;
     }
     if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
 
     // rare path
     const int z = opaque_zero();
-    const int jj = j + z;
-    const int h = (lane >> 5) + z;
-    const bool colValid = jj < pr.nB;
+    const int ln = lane + z;
     if (!(thr_m > -INFINITY)) { // norms out of range: no bound holds, score the pair cell by cell
         wq.n = wq.cap + 1;
         return;
@@ -258,32 +306,32 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
     if (!DOT && wq.n * 2 < wq.cap) {
         u64 bits = 0;
 #pragma unroll
-        for (int t = 0; t < RT; t++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) bits |= (u64)(acc[t][q] > thr_m) << (t * 16 + q);
-        if (!colValid) bits = 0;
+        for (int idx = 0; idx < NV; idx++) bits |= (u64)(acc.get(idx) > thr_m) << idx;
         while (__builtin_amdgcn_ballot_w64(bits != 0) != 0) {
             const bool has = bits != 0;
             const int bit = has ? __builtin_ctzll(bits) : 0;
             bits &= bits - 1;
-            const int q = bit & 15;
-            const int i = rowBase + (bit >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            queue_push(wq, has && i < pr.nA, i, jj, lane);
+            const int i = rowBase + AccT::row(bit, ln);
+            const int jj = colBase + AccT::col(bit, ln);
+            queue_push(wq, has && i < pr.nA && jj < pr.nB, i, jj, lane);
         }
         return;
     }
 
-    const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
     const float thrp = fmaxf(g.threshold, 0.0f);
-    unsigned *colSlot = g.runMax + pr.bestCol + (colValid ? jj : 0);
-    const unsigned colKey0 = colValid ? *colSlot : 0u;
-    unsigned colKey = colKey0;
 #pragma unroll
-    for (int t = 0; t < RT; t++)
+    for (int grp = 0; grp < AccT::NGROUP; grp++) {
+        const int jj = colBase + AccT::col(grp * AccT::GROUP, ln);
+        const bool colValid = jj < pr.nB;
+        const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
+        unsigned *colSlot = g.runMax + pr.bestCol + (colValid ? jj : 0);
+        const unsigned colKey0 = colValid ? *colSlot : 0u;
+        unsigned colKey = colKey0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const float v = acc[t][q];
-            const int i = rowBase + t * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        for (int k = 0; k < AccT::GROUP; k++) {
+            const int idx = grp * AccT::GROUP + k;
+            const float v = acc.get(idx);
+            const int i = rowBase + AccT::row(idx, ln);
             bool take = false;
             if (colValid && i < pr.nA && (DOT || v > thr_m)) {
                 float lo = v - SIM_MARGIN, hi = v + SIM_MARGIN;
@@ -309,14 +357,24 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
             }
             queue_push(wq, take, i, jj, lane);
         }
-    if (colKey > colKey0) atomicMax(colSlot, colKey);
+        if (colKey > colKey0) atomicMax(colSlot, colKey);
+    }
 }
 
-template <int RT> __device__ __forceinline__ void keep_alive(const float16v (&acc)[RT])
+template <int RT> __device__ __forceinline__ void keep_alive(const Acc32<RT> &acc)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int t = 0; t < RT; t++) asm volatile("" ::"v"(acc[t]));
+    for (int t = 0; t < RT; t++) asm volatile("" ::"v"(acc.a[t]));
+#endif
+}
+template <int RT> __device__ __forceinline__ void keep_alive(const Acc16<RT> &acc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int t = 0; t < 2 * RT; t++) asm volatile("" ::"v"(acc.a[c][t]));
 #endif
 }
 
@@ -328,13 +386,14 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // PIPE = 1: two accumulator sets; the candidate test of one 32-column step is issued among the
 // MFMAs of the next one.
 // ABL: timing-only ablations (wrong results): 1 = no staging and no barrier, 2 = no candidate test.
-template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL>
+template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL, int STAGES, int MF16>
 __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
 {
     constexpr int NSUB = BN_ / 32;
     constexpr int DMA = BN_ * 256 / 1024 / WAVES; // LDS-DMA instructions per wave per step
     static_assert(BN_ * 256 % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BN_ * 256];
+    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * 256];
 
     const int2 w = g.work[blockIdx.x];
     if (w.x < 0) return;
@@ -347,12 +406,16 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     const _Float16 *A16 = g.desc16 + (size_t)(pr.rowA16 + rowBase) * KDIM;
     const unsigned char *B16 = reinterpret_cast<const unsigned char *>(g.desc16 + (size_t)pr.rowB16 * KDIM);
 
-    half8 a[RT][8];
+    // A fragments.  32x32x16: a[t][s] = rows 32t + (l & 31), k = 16s + 8(l >> 5) .. +7.
+    //               16x16x32: a[t][s] = rows 16t + (l & 15), k = 32s + 8(l >> 4) .. +7.
+    constexpr int NA_T = MF16 ? 2 * RT : RT, NA_S = MF16 ? 4 : 8;
+    half8 a[NA_T][NA_S];
 #pragma unroll
-    for (int t = 0; t < RT; t++)
+    for (int t = 0; t < NA_T; t++)
 #pragma unroll
-        for (int s = 0; s < 8; s++)
-            a[t][s] = *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
+        for (int s = 0; s < NA_S; s++)
+            a[t][s] = MF16 ? *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 16 + (lane & 15)) * KDIM + s * 32 + (lane >> 4) * 8)
+                           : *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
 
     const int nChunks = (pr.nB + BN_ - 1) / BN_;
     // the bound is the same for the whole block: keep it (and the branch on it) scalar
@@ -372,16 +435,27 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
         for (int u = 0; u < DMA; u++)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + srcOff[u]), (lptr_t)&lds[buf][(wave * DMA + u) * 1024], 16, 0, 0);
     };
-    auto mfma_step = [&](float16v (&acc)[RT], int buf, int sub) {
+    using AccT = typename std::conditional<MF16 != 0, Acc16<RT>, Acc32<RT>>::type;
+    auto mfma_step = [&](AccT &acc, int buf, int sub) {
+        acc.zero();
+        if constexpr (MF16 != 0) {
 #pragma unroll
-        for (int t = 0; t < RT; t++)
+            for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc[t][q] = 0.0f;
+                for (int s = 0; s < 4; s++) {
+                    const int row = sub * 32 + ct * 16 + (lane & 15);
+                    const half8 b = *reinterpret_cast<const half8 *>(&lds[buf][row * 256 + (((4 * s + (lane >> 4)) ^ (row & 15)) << 4)]);
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const half8 b = *reinterpret_cast<const half8 *>(&lds[buf][(sub * 32 + r) * 256 + (((2 * s + h) ^ (r & 15)) << 4)]);
+                    for (int t = 0; t < 2 * RT; t++)
+                        acc.a[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][s], b, acc.a[ct][t], 0, 0, 0);
+                }
+        } else {
 #pragma unroll
-            for (int t = 0; t < RT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][s], b, acc[t], 0, 0, 0);
+            for (int s = 0; s < 8; s++) {
+                const half8 b = *reinterpret_cast<const half8 *>(&lds[buf][(sub * 32 + r) * 256 + (((2 * s + h) ^ (r & 15)) << 4)]);
+#pragma unroll
+                for (int t = 0; t < RT; t++) acc.a[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][s], b, acc.a[t], 0, 0, 0);
+            }
         }
     };
     // this wave's slice of the pair's candidate list
@@ -391,31 +465,43 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     wq.cap = g.candCap / nQueues;
     wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
     wq.n = 0;
-    auto test = [&](const float16v (&acc)[RT], int j) {
+    auto test = [&](const AccT &acc, int colBase) {
         if constexpr ((ABL & 2) != 0)
             keep_alive<RT>(acc);
         else
-            sim_epilogue<RT, DOT>(g, pr, acc, rowBase, j, lane, thr_m, wq);
+            sim_epilogue<AccT, DOT>(g, pr, acc, rowBase, colBase, lane, thr_m, wq);
     };
 
-    dma_issue(0, 0);
-    __syncthreads();
-
-    float16v accA[RT], accB[RT];
+    AccT accA, accB;
     int jPrev = 0x40000000; // "no previous step": beyond every column
-    if (PIPE) {
-#pragma unroll
-        for (int t = 0; t < RT; t++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) accB[t][q] = 0.0f;
-    }
-
+    if (PIPE) accB.zero();
+    // STAGES == 2: step c+1 is in flight while step c is consumed; one barrier per step, after it.
+    // STAGES == 3: steps c+1 and c+2 are in flight.  The barrier at the top of iteration c says:
+    // every wave's share of step c has landed (each wave waits until at most its newest DMA group,
+    // step c+1, is outstanding) and every wave is done reading the buffer of step c-1, which is
+    // the one step c+2 overwrites.
+    dma_issue(0, 0);
+    if (STAGES == 2)
+        __syncthreads();
+    else if (nChunks > 1)
+        dma_issue(1, 1);
+    int buf = 0;
     for (int c = 0; c < nChunks; c++) {
-        const int buf = (ABL & 1) ? 0 : (c & 1);
-        if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
+        if (STAGES == 2) {
+            if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
+        } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (c + 1 < nChunks)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            __builtin_amdgcn_s_barrier();
+            if (c + 2 < nChunks) dma_issue(c + 2, (buf == 0) ? 2 : buf - 1);
+        }
 #pragma unroll
         for (int sub = 0; sub < NSUB; sub += 2) {
-            const int j0 = c * BN_ + sub * 32 + r;
+            const int j0 = c * BN_ + sub * 32;
             if (PIPE) {
                 mfma_step(accA, buf, sub);
                 test(accB, jPrev);
@@ -429,7 +515,14 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
                 test(accA, j0 + 32);
             }
         }
-        if (!(ABL & 1)) __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
+        if (STAGES == 2) {
+            if (!(ABL & 1)) {
+                __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
+                buf ^= 1;
+            }
+        } else {
+            buf = (buf == 2) ? 0 : buf + 1;
+        }
     }
     if (PIPE) test(accB, jPrev);
     if (lane == 0) {
@@ -445,22 +538,24 @@ struct SimVariant {
     void (*dot)(const MatchArgs);
     const char *name;
 };
-#define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL)                                                        \
-    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL>,                \
-     match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, true, ABL>,                                               \
-     "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL}
+#define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES, MF16)                                          \
+    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, MF16>,  \
+     match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, true, ABL, STAGES, MF16>,                                 \
+     "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL "_st" #STAGES "_mf16" #MF16}
 static const SimVariant kSimVariants[] = {
-    SIM_VARIANT(2, 8, 128, 2, 0, 0), // 0: 8 waves x 64 rows, one block per CU
-    SIM_VARIANT(2, 8, 128, 4, 0, 0), // 1: same, two blocks per CU (<= 128 VGPRs)
-    SIM_VARIANT(2, 8, 128, 2, 1, 0), // 2: pipelined candidate test
-    SIM_VARIANT(4, 8, 128, 2, 0, 0), // 3: 8 waves x 128 rows
-    SIM_VARIANT(2, 4, 64, 3, 0, 0),  // 4: 4 waves x 64 rows, three blocks per CU
-    SIM_VARIANT(2, 4, 64, 4, 0, 0),  // 5
-    SIM_VARIANT(2, 8, 256, 2, 0, 0), // 6
-    SIM_VARIANT(2, 4, 128, 2, 0, 0), // 7
-    SIM_VARIANT(2, 8, 128, 2, 0, 1), // 8: ablation, no staging
-    SIM_VARIANT(2, 8, 128, 2, 0, 2), // 9: ablation, no candidate test
-    SIM_VARIANT(2, 8, 128, 2, 0, 3), // 10: ablation, neither
+    SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 0), // 0: 8 waves x 64 rows, one block per CU
+    SIM_VARIANT(2, 8, 128, 2, 1, 0, 2, 0), // 1: pipelined candidate test
+    SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 1), // 2: 16x16x32 MFMA
+    SIM_VARIANT(2, 8, 128, 2, 1, 0, 2, 1), // 3
+    SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 0),  // 4: 4 waves x 64 rows, three blocks per CU
+    SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 1),  // 5: same with 16x16x32 MFMA
+    SIM_VARIANT(2, 4, 64, 2, 1, 0, 2, 1),  // 6
+    SIM_VARIANT(2, 4, 64, 3, 0, 0, 3, 1),  // 7
+    SIM_VARIANT(4, 4, 64, 2, 0, 0, 2, 1),  // 8
+    SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 0),  // 9: ablation of 4, no candidate test
+    SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 0),  // 10: ablation of 4, neither staging nor test
+    SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 1),  // 11: ablation of 5, no candidate test
+    SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 1),  // 12: ablation of 5, neither
 };
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
@@ -485,6 +580,99 @@ __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
     for (int k = lane; k < n; k += 64) {
         const uint2 c = list[k];
         fold_cell(g, pr, (int)c.x, (int)c.y);
+    }
+}
+
+// The same exact pass for dim == 128 with coalesced loads: a wave takes 64 candidates, brings
+// their descriptor rows in through LDS 32 floats at a time (eight lanes fetch one 128-byte piece
+// of one row), and every lane then runs its own candidate's multiply-add chain out of LDS in
+// index order.  Candidates of a pair are numbered across its slices with a prefix sum so that
+// waves are full.
+#define CAND_ROWB 272 // LDS bytes per candidate per step: 2 x 128 B of data + 16 B pad (bank spread)
+__global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
+{
+    __shared__ int prefix[1025];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][64 * CAND_ROWB];
+    __shared__ uint2 ij[4][64];
+
+    const int p = blockIdx.y;
+    if (g.pairOvf[p]) return; // match_exact_kernel scores the whole pair
+    const PairRec pr = g.pairs[p];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nQueues = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
+    const int cap = g.candCap / nQueues;
+
+    // exclusive prefix of the slice counts (nQueues <= 1024)
+    for (int q = tid; q < 1024; q += 256) prefix[q + 1] = (q < nQueues) ? g.candCount[p * g.maxQueues + q] : 0;
+    if (tid == 0) prefix[0] = 0;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = tid + 256 * u + 1;
+            v[u] = (q > d) ? prefix[q - d] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) prefix[tid + 256 * u + 1] += v[u];
+        __syncthreads();
+    }
+    const int total = prefix[nQueues];
+    if (blockIdx.x == 0 && tid == 0 && total > 0) atomicAdd(&g.stats[0], (u64)total);
+
+    const float *A32 = g.desc32 + (size_t)pr.rowA32 * 128;
+    const float *B32 = g.desc32 + (size_t)pr.rowB32 * 128;
+    unsigned char *st = stage[wave];
+    for (int tile = blockIdx.x * 4 + wave; tile * 64 < total; tile += gridDim.x * 4) {
+        const int c = tile * 64 + lane;
+        uint2 me = make_uint2(0, 0);
+        if (c < total) {
+            int lo = 0, hi = nQueues; // last q with prefix[q] <= c
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (prefix[mid] <= c) lo = mid; else hi = mid;
+            }
+            me = g.cand[(size_t)p * g.candCap + (size_t)lo * cap + (c - prefix[lo])];
+        }
+        ij[wave][lane] = me;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        float dot = 0.0f;
+        for (int kc = 0; kc < 4; kc++) {
+            float4 v[16];
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int rc = it * 8 + (lane >> 3); // row piece: candidate rc >> 1, image rc & 1
+                const uint2 who = ij[wave][rc >> 1];
+                const float *src = (rc & 1) ? B32 + (size_t)who.y * 128 : A32 + (size_t)who.x * 128;
+                v[it] = *reinterpret_cast<const float4 *>(src + kc * 32 + (lane & 7) * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int rc = it * 8 + (lane >> 3);
+                *reinterpret_cast<float4 *>(st + (rc >> 1) * CAND_ROWB + (rc & 1) * 128 + (lane & 7) * 16) = v[it];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float4 *ma = reinterpret_cast<const float4 *>(st + lane * CAND_ROWB);
+            const float4 *mb = reinterpret_cast<const float4 *>(st + lane * CAND_ROWB + 128);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float4 av = ma[e], bv = mb[e];
+                dot = __fadd_rn(dot, __fmul_rn(av.x, bv.x));
+                dot = __fadd_rn(dot, __fmul_rn(av.y, bv.y));
+                dot = __fadd_rn(dot, __fmul_rn(av.z, bv.z));
+                dot = __fadd_rn(dot, __fmul_rn(av.w, bv.w));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (c < total) fold_dot(g, pr, (int)me.x, (int)me.y, dot);
     }
 }
 
@@ -928,8 +1116,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             hipLaunchKernelGGL(metric == SFM_METRIC_COSINE ? variant.cos : variant.dot, dim3(nblk),
                                dim3(variant.threads), 0, st, g);
             SFM_HIP(ctx, sfm_span_end(ctx, 0));
-            if (candCap > 0)
-                hipLaunchKernelGGL(match_cand_kernel, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
+            if (candCap > 0) {
+                if (set->dim == 128 && maxQueues <= 1024)
+                    hipLaunchKernelGGL(match_cand128_kernel, dim3(4, np), dim3(256), 0, st, g);
+                else
+                    hipLaunchKernelGGL(match_cand_kernel, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
+            }
             hipLaunchKernelGGL(match_overflow_list_kernel, dim3(1), dim3(256), 0, st, g, np);
             hipLaunchKernelGGL(match_exact_kernel, dim3(4 * ctx->n_cus), dim3(256), 0, st, g);
         }

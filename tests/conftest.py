@@ -25,5 +25,7 @@ def ctx():
     """A device context of the HIP library; GPU tests only."""
     from sfm_amd import capi
     c = capi.Context(0)
+    if os.environ.get("SFM_SIM_VARIANT"):  # run the suite against another similarity-kernel instance
+        c.set_option("sim_variant", int(os.environ["SFM_SIM_VARIANT"]))
     yield c
     c.close()
