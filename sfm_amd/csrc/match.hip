@@ -59,7 +59,8 @@ struct MatchArgs {
     const int2 *work;     // (pair in chunk, row block), -1 = no work
     uint2 *cand;          // [pairs in chunk][candCap]
     int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
-    int *pairOvf;         // [pairs in chunk]: 1 = a slice overflowed, score the pair cell by cell
+    int *pairOvf;         // [pairs in chunk]: 1 = a slice overflowed in the strict pass, 2 = in the general pass
+    int onlyFlagged;      // general pass over the pairs flagged 1 only
     int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
     u64 *best;            // row keys and column keys of the chunk
     unsigned *runMax;     // running lower bounds of each row's / column's best similarity (ordered keys)
@@ -272,14 +273,15 @@ template <int RT> struct Acc16 {
 // Candidate test of one 32-column step and the rare emission path.  colBase = first column of
 // the step.
 //
-// Normal mode: every cell above the bound is queued.  Once a wave has queued half its slice
-// (loose thresholds, where most cells clear the bound), and always for the dot metric, a cell is
-// queued only if it can still be the best of its row or of its column: its upper bound must reach
+// Strict instances (GENERAL = false) queue every cell above the bound; a slice that overflows
+// flags the pair, and the general instance then redoes the flagged pairs.  In the general
+// instance, once a wave has queued half its slice (loose thresholds, where most cells clear the
+// bound), and always for the dot metric, a cell is queued only if it can still be the best of its row or of its column: its upper bound must reach
 // the largest lower bound seen so far there (runMax, ordered keys, 0 = nothing yet).  The true
 // arg-max always passes: its upper bound is at least its exact value, which is at least every
 // other cell's exact value, which is at least that cell's lower bound.  Racing updates only make
 // the test more permissive.
-template <typename AccT, bool DOT>
+template <typename AccT, bool DOT, bool GENERAL>
 __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
                                              int colBase, int lane, float thr_m, WaveQueue &wq)
 {
@@ -303,7 +305,7 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         return;
     }
 
-    if (!DOT && wq.n * 2 < wq.cap) {
+    if (!GENERAL || (!DOT && wq.n * 2 < wq.cap)) {
         u64 bits = 0;
 #pragma unroll
         for (int idx = 0; idx < NV; idx++) bits |= (u64)(acc.get(idx) > thr_m) << idx;
@@ -317,6 +319,7 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         }
         return;
     }
+    if constexpr (!GENERAL) return;
 
     const float thrp = fmaxf(g.threshold, 0.0f);
 #pragma unroll
@@ -325,7 +328,8 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         const bool colValid = jj < pr.nB;
         const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
         unsigned *colSlot = g.runMax + pr.bestCol + (colValid ? jj : 0);
-        const unsigned colKey0 = colValid ? *colSlot : 0u;
+        // agent-scope loads: other CUs' updates are in L2, this CU's vector L1 may hold an older line
+        const unsigned colKey0 = colValid ? __hip_atomic_load(colSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         unsigned colKey = colKey0;
 #pragma unroll
         for (int k = 0; k < AccT::GROUP; k++) {
@@ -344,7 +348,7 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
                 }
                 if (cnd) {
                     unsigned *rowSlot = g.runMax + pr.bestRow + i;
-                    const unsigned rowKey = *rowSlot;
+                    const unsigned rowKey = __hip_atomic_load(rowSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool rowOk = rowKey == 0 || hi >= ordered_value(rowKey);
                     const bool colOk = colKey == 0 || hi >= ordered_value(colKey);
                     if (rowOk || colOk) {
@@ -386,7 +390,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // PIPE = 1: two accumulator sets; the candidate test of one 32-column step is issued among the
 // MFMAs of the next one.
 // ABL: timing-only ablations (wrong results): 1 = no staging and no barrier, 2 = no candidate test.
-template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL, int STAGES, int MF16>
+template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL, int STAGES, int MF16, bool GENERAL>
 __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
 {
     constexpr int NSUB = BN_ / 32;
@@ -395,8 +399,10 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers");
     __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * 256];
 
+    static_assert(GENERAL || !DOT, "the dot metric needs the general instance");
     const int2 w = g.work[blockIdx.x];
     if (w.x < 0) return;
+    if (g.onlyFlagged && g.pairOvf[w.x] != 1) return; // second pass: pairs the strict pass gave up on
     const PairRec pr = g.pairs[w.x];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
         if constexpr ((ABL & 2) != 0)
             keep_alive<RT>(acc);
         else
-            sim_epilogue<AccT, DOT>(g, pr, acc, rowBase, colBase, lane, thr_m, wq);
+            sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, thr_m, wq);
     };
 
     AccT accA, accB;
@@ -527,20 +533,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     if (PIPE) test(accB, jPrev);
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
-        if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = 1;
+        if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = GENERAL ? 2 : 1;
     }
 }
 
 // The instances that can be selected with sfm_ctx_set_option("sim_variant").
 struct SimVariant {
     int blockRows, threads;
-    void (*cos)(const MatchArgs);
+    void (*strict)(const MatchArgs);  // cosine, every cell above the bound is queued
+    void (*general)(const MatchArgs); // cosine with the row/column-best filter
     void (*dot)(const MatchArgs);
     const char *name;
 };
-#define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES, MF16)                                          \
-    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, MF16>,  \
-     match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, true, ABL, STAGES, MF16>,                                 \
+#define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES, MF16)                                              \
+    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, MF16, false>, \
+     match_sim_kernel<RT, WAVES, BN_, 2, 0, false, ABL, STAGES, MF16, true>,                                    \
+     match_sim_kernel<RT, WAVES, BN_, 2, 0, true, ABL, STAGES, MF16, true>,                                     \
      "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL "_st" #STAGES "_mf16" #MF16}
 static const SimVariant kSimVariants[] = {
     SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 0), // 0: 8 waves x 64 rows, one block per CU
@@ -551,7 +559,7 @@ static const SimVariant kSimVariants[] = {
     SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 1),  // 5: same with 16x16x32 MFMA
     SIM_VARIANT(2, 4, 64, 2, 1, 0, 2, 1),  // 6
     SIM_VARIANT(2, 4, 64, 3, 0, 0, 3, 1),  // 7
-    SIM_VARIANT(4, 4, 64, 2, 0, 0, 2, 1),  // 8
+    SIM_VARIANT(2, 4, 64, 4, 0, 0, 2, 1),  // 8: four blocks per CU (<= 128 VGPRs)
     SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 0),  // 9: ablation of 4, no candidate test
     SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 0),  // 10: ablation of 4, neither staging nor test
     SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 1),  // 11: ablation of 5, no candidate test
@@ -566,7 +574,7 @@ static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVaria
 __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
 {
     const int p = blockIdx.y;
-    if (g.pairOvf[p]) return; // match_exact_kernel scores the whole pair
+    if (g.pairOvf[p] == 2) return; // match_exact_kernel scores the whole pair
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= g.maxQueues) return;
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
     __shared__ uint2 ij[4][64];
 
     const int p = blockIdx.y;
-    if (g.pairOvf[p]) return; // match_exact_kernel scores the whole pair
+    if (g.pairOvf[p] == 2) return; // match_exact_kernel scores the whole pair
     const PairRec pr = g.pairs[p];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nQueues = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(256) void match_overflow_list_kernel(const MatchArg
     if (threadIdx.x == 0) n = 0;
     __syncthreads();
     for (int p = threadIdx.x; p < nPairs; p += blockDim.x)
-        if (g.pairOvf[p]) g.ovfList[1 + atomicAdd(&n, 1)] = p;
+        if (g.pairOvf[p] == 2) g.ovfList[1 + atomicAdd(&n, 1)] = p;
     __syncthreads();
     if (threadIdx.x == 0) {
         g.ovfList[0] = n;
@@ -1113,9 +1121,15 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         const int nblk = chunkWorkCount[ci];
         if (nblk > 0) {
             SFM_HIP(ctx, sfm_span_begin(ctx, 0));
-            hipLaunchKernelGGL(metric == SFM_METRIC_COSINE ? variant.cos : variant.dot, dim3(nblk),
+            g.onlyFlagged = 0;
+            hipLaunchKernelGGL(metric == SFM_METRIC_COSINE ? variant.strict : variant.dot, dim3(nblk),
                                dim3(variant.threads), 0, st, g);
             SFM_HIP(ctx, sfm_span_end(ctx, 0));
+            if (metric == SFM_METRIC_COSINE) { // pairs whose slices overflowed: again, with the filter
+                g.onlyFlagged = 1;
+                hipLaunchKernelGGL(variant.general, dim3(nblk), dim3(variant.threads), 0, st, g);
+                g.onlyFlagged = 0;
+            }
             if (candCap > 0) {
                 if (set->dim == 128 && maxQueues <= 1024)
                     hipLaunchKernelGGL(match_cand128_kernel, dim3(4, np), dim3(256), 0, st, g);
