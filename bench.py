@@ -150,7 +150,8 @@ def main():
             "bound": "mfma", "kernel": "match_sim_kernel",
             "achieved": round(achieved_tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved_tflops / PEAK_F16_TFLOPS, 4),
-            "traffic": None,
+            "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1)),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass, profiles/r1_pmc_traffic.json)",
             "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4), "launches": kernel_launches,
             "flops_per_pair": flops_per_pair,
         },
@@ -169,6 +170,18 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(pairs_per_launch):
+    """HBM bytes per launch of the similarity kernel from the committed PMC pass (FETCH_SIZE and
+    WRITE_SIZE are collected by rocprofv3 in separate runs of this script, not inline), scaled to
+    this run's pairs per launch; None if the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return round(t["hbm_bytes_per_pair"] * pairs_per_launch)
 
 
 def bench_ransac(ctx, args, rank, world, dist, local_rank):
