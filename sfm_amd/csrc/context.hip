@@ -67,6 +67,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "hyps_per_launch")) {
         if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "hyps_per_launch must be >= 0");
         ctx->hyps_per_launch = value;
+    } else if (!strcmp(key, "ransac_filter")) {
+        ctx->ransac_filter = value != 0;
     } else if (!strcmp(key, "sim_variant")) {
         if (value < 0 || value >= sfm_num_sim_variants())
             SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "sim_variant must be in [0, %d)", sfm_num_sim_variants());

@@ -21,6 +21,8 @@
 // Jacobi for the 3x3 SVD, normal equations for the 3x2 least squares.
 #include "common.h"
 
+#include <cmath>
+
 #pragma clang fp contract(off)
 
 #define SCORE_CH 256 // correspondences staged in LDS per step
@@ -43,6 +45,8 @@ struct RansacArgs {
     const int64_t *inlOff;  // [P+1]
     int32_t *inliers;
     double K[9]; // column-major
+    double Ki[4]; // inverse of K's upper-left 2x2 block, row-major (valid when filter != 0)
+    int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
     double maxSqErr;
     double successProb;
     int H;
@@ -156,7 +160,10 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     r[6] = (g.K[1] * a.x + g.K[4] * a.y) + g.K[7];
     r[7] = (g.K[0] * b.x + g.K[3] * b.y) + g.K[6];
     r[8] = (g.K[1] * b.x + g.K[4] * b.y) + g.K[7];
-    r[9] = 0.0;
+    // x1h.x1h for the scoring kernel's pre-test, or +inf for a correspondence it must not skip
+    const double big = 1e6;
+    const bool tame = fabs(r[5]) <= big && fabs(r[6]) <= big && fabs(r[7]) <= big && fabs(r[8]) <= big;
+    r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -439,11 +446,14 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
     Pose P;
     load_pose(g.pose12 + ((size_t)p * g.H + (active ? h : 0)) * 12, P);
     double E[3][3];
-    if (LOSS == SFM_LOSS_SAMPSON) essential_from_pose(P, E);
+    essential_from_pose(P, E);
     double K[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) K[i] = g.K[i];
     const double thr = g.maxSqErr;
+    const double thr4 = 4.0 * thr;
+    const bool filterOn = g.filter != 0;
+    const double Ki00 = g.Ki[0], Ki01 = g.Ki[1], Ki10 = g.Ki[2], Ki11 = g.Ki[3];
 
     int count = 0;
     double tot = 0.0;
@@ -454,14 +464,43 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
         __syncthreads();
         for (int kk = 0; kk < m; kk++) {
             const double *r = rec + kk * REC_D;
-            double e;
-            if (LOSS == SFM_LOSS_SAMPSON)
-                e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
-            else
-                e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
-            if (e < thr) { // RANSAC.cpp:216-220
-                count++;
-                tot += e;
+            if (LOSS == SFM_LOSS_SAMPSON) {
+                const double e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+                if (e < thr) {
+                    count++;
+                    tot += e;
+                }
+                continue;
+            }
+            // Pre-test.  Whatever depth the triangulation picks, the point lies on the ray of
+            // x1, so its image in camera 2 lies on the epipolar line of x1; the camera-2
+            // reprojection error is therefore at least the distance from the observation to that
+            // line.  If that distance is at least twice sqrt(maxSquaredError) the correspondence
+            // cannot be an inlier of this hypothesis and the exact evaluation is skipped.  Guards:
+            // the line must be well defined (x1 not within 1e-3 of the epipole: there the
+            // projection of the triangulated point is unstable), the residual must stand clear of
+            // its own rounding noise, and the observation must be an ordinary pixel (r[9]).
+            bool need = true;
+            if (filterOn) {
+                const double x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+                const double m0 = fma(E[0][0], x1, fma(E[0][1], y1, E[0][2]));
+                const double m1 = fma(E[1][0], x1, fma(E[1][1], y1, E[1][2]));
+                const double m2 = fma(E[2][0], x1, fma(E[2][1], y1, E[2][2]));
+                const double num = fma(x2, m0, fma(y2, m1, m2));
+                const double l0 = fma(Ki00, m0, Ki10 * m1); // (K^-T m) rows 0, 1: the line in pixels
+                const double l1 = fma(Ki01, m0, Ki11 * m1);
+                const double den2 = fma(l0, l0, l1 * l1);
+                const double msq = fma(m0, m0, fma(m1, m1, m2 * m2));
+                const double mag = fma(fabs(x2), fabs(m0), fma(fabs(y2), fabs(m1), fabs(m2)));
+                const bool skip = (num * num >= thr4 * den2) && (msq >= 1e-6 * r[9]) && (fabs(num) >= 1e-9 * mag);
+                need = !skip;
+            }
+            if (need) {
+                const double e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+                if (e < thr) { // RANSAC.cpp:216-220
+                    count++;
+                    tot += e;
+                }
             }
         }
         __syncthreads();
@@ -738,6 +777,20 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.inlOff = b->inlOff.as<int64_t>();
     g.inliers = b->inliers.as<int32_t>();
     for (int i = 0; i < 9; i++) g.K[i] = K[i];
+    {
+        // K column-major: K(r,c) = K[r + 3c].  The pre-test needs the last row to be (0, 0, 1)
+        // (then observations K*(x,y,1) are pixels with unit third component) and an invertible
+        // upper-left block.
+        const double k00 = K[0], k10 = K[1], k01 = K[3], k11 = K[4];
+        const double det2 = k00 * k11 - k01 * k10;
+        const bool ok = K[2] == 0.0 && K[5] == 0.0 && K[8] == 1.0 && det2 != 0.0 && std::isfinite(det2) &&
+                        std::isfinite(1.0 / det2) && ctx->ransac_filter != 0;
+        g.filter = ok ? 1 : 0;
+        g.Ki[0] = ok ? k11 / det2 : 0.0;  // Kinv(0,0)
+        g.Ki[1] = ok ? -k01 / det2 : 0.0; // Kinv(0,1)
+        g.Ki[2] = ok ? -k10 / det2 : 0.0; // Kinv(1,0)
+        g.Ki[3] = ok ? k00 / det2 : 0.0;  // Kinv(1,1)
+    }
     g.maxSqErr = maxSqErr;
     g.successProb = successProb;
     g.H = n_hyp;

@@ -176,3 +176,43 @@ def test_stress_shape_is_deterministic(ctx):
     top = np.flatnonzero(c == c.max())
     assert a["best_h"] == top[np.argmin(a["toterr"][top])]
     assert len(a["inliers"]) == c.max()
+
+
+def test_pretest_never_changes_a_result(ctx, oracle):
+    """The scoring kernel's epipolar pre-test only skips evaluations that cannot be inliers:
+    with it on and off, per-hypothesis counts and error sums are identical, also for
+    correspondences at the epipole, far outside the image, and with a loose threshold."""
+    tv = synth.two_view(3000, inlier_ratio=0.5, seed=91, noise_px=1.0)
+    x, y = tv["x"].copy(), tv["y"].copy()
+    S = synth.sample_table(3000, 512, seed=92)
+    # put some observations on / next to the epipoles of the planted pose and far away
+    R, T = tv["R"], tv["T"]
+    e1 = -R.T @ T
+    e2 = T
+    for k in range(20):
+        x[k] = e1[:2] / e1[2] + (k % 5) * 1e-7
+        y[20 + k] = e2[:2] / e2[2] + (k % 7) * 1e-9
+    x[50] = [1e9, -1e9]
+    y[51] = [1e7, 2e7]
+    x[52] = y[52] = [0.0, 0.0]
+    for thr in (1.0, 1e4, 1e-6):
+        res = []
+        for flt in (1, 0):
+            ctx.set_option("ransac_filter", flt)
+            res.append(ctx.ransac_pair(x, y, tv["K"], S, max_sq_err=thr, adaptive=False))
+        ctx.set_option("ransac_filter", 1)
+        assert np.array_equal(res[0]["counts"], res[1]["counts"])
+        assert np.array_equal(res[0]["toterr"].view(np.uint64), res[1]["toterr"].view(np.uint64))
+        assert np.array_equal(res[0]["inliers"], res[1]["inliers"])
+        exp = oracle.ransac(x, y, tv["K"], S, max_sq_err=thr, adaptive=False)
+        assert np.array_equal(res[0]["counts"], exp["counts"]) and np.array_equal(res[0]["inliers"], exp["inliers"])
+
+
+def test_pretest_is_off_for_unusual_intrinsics(ctx, oracle):
+    tv = synth.two_view(600, inlier_ratio=0.5, seed=93)
+    K = tv["K"].copy()
+    K[2] = [1e-5, -2e-5, 1.0]  # last row not (0, 0, 1): observations are not plain pixels
+    S = synth.sample_table(600, 128, seed=94)
+    got = ctx.ransac_pair(tv["x"], tv["y"], K, S, max_sq_err=2.0, adaptive=False)
+    exp = oracle.ransac(tv["x"], tv["y"], K, S, max_sq_err=2.0, adaptive=False)
+    assert_same_run(got, exp)
