@@ -327,6 +327,7 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         const int jj = colBase + AccT::col(grp * AccT::GROUP, ln);
         const bool colValid = jj < pr.nB;
         const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
+        const double2 pb = g.pts[pr.rowB32 + (colValid ? jj : 0)];
         unsigned *colSlot = g.runMax + pr.bestCol + (colValid ? jj : 0);
         // agent-scope loads: other CUs' updates are in L2, this CU's vector L1 may hold an older line
         const unsigned colKey0 = colValid ? __hip_atomic_load(colSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -339,12 +340,16 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
             bool take = false;
             if (colValid && i < pr.nA && (DOT || v > thr_m)) {
                 float lo = v - SIM_MARGIN, hi = v + SIM_MARGIN;
-                bool cnd = true;
+                // A cell outside the pixel gate (match.cpp:45) is not part of any arg-max: it must
+                // neither be queued nor raise a running bound.
+                const double2 pa = g.pts[pr.rowA32 + i];
+                const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
+                bool cnd = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < (double)g.maxDistSq;
                 if (DOT) { // dot = approx * sA * sB within 1e-3 * sA * sB
                     const float p = g.norms[pr.rowA32 + i] * sB;
                     lo *= p;
                     hi *= p;
-                    cnd = hi > thrp;
+                    cnd = cnd && hi > thrp;
                 }
                 if (cnd) {
                     unsigned *rowSlot = g.runMax + pr.bestRow + i;

@@ -187,3 +187,18 @@ def test_full_size_properties(ctx):
     assert set(map(tuple, ab)) == set(map(tuple, ba[:, ::-1]))
     assert np.array_equal(cc[:, 0], cc[:, 1]) and len(cc) > 8000
     s.close()
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.0])
+def test_loose_threshold_with_tight_pixel_gate(ctx, oracle, thr):
+    """Most cells clear the similarity threshold but few are inside the pixel gate: a row's most
+    similar cell is usually outside the gate and must not shadow the best cell inside it."""
+    dA, pA, dB, pB = two_images(900, 1000, shared=0.4, seed=41)
+    dA = np.maximum(dA, 15)
+    dB = np.maximum(dB, 15)
+    ctx.set_option("cand_capacity", 4096)  # force the filtered second pass
+    try:
+        for gate in (60.0 * 60.0, 300.0 * 300.0, 1500.0 * 1500.0):
+            check_pair(ctx, oracle, dA, pA, dB, pB, thr, gate)
+    finally:
+        ctx.set_option("cand_capacity", 32768)
