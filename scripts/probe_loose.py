@@ -8,7 +8,7 @@ ctx = capi.Context(0)
 s = ctx.imageset(c, d, p)
 pl = synth.exhaustive_pairs(n_img)
 for thr in [float(x) for x in sys.argv[3].split(",")]:
-    for cap in [32768, 262144]:
+    for cap in [262144, 524288]:
         ctx.set_option("cand_capacity", cap)
         res = None
         for it in range(2):

@@ -15,7 +15,7 @@ struct sfm_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     // tunables
-    int64_t cand_capacity = 32768;   // candidate slots per image pair
+    int64_t cand_capacity = 524288;  // candidate slots per image pair
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
     int64_t hyps_per_launch = 0;     // 0 = all hypotheses of a RANSAC call in one launch
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test

@@ -61,9 +61,9 @@ struct MatchArgs {
     int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
     int *pairOvf;         // [pairs in chunk]: 1 = a slice overflowed in the strict pass, 2 = in the general pass
     int onlyFlagged;      // general pass over the pairs flagged 1 only
+    int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
     int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
     u64 *best;            // row keys and column keys of the chunk
-    unsigned *runMax;     // running lower bounds of each row's / column's best similarity (ordered keys)
     int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
     u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell
     int candCap;
@@ -270,32 +270,58 @@ template <int RT> struct Acc16 {
     __device__ static __forceinline__ int col(int idx, int lane) { return (idx / GROUP) * 16 + (lane & 15); }
 };
 
+// What the general instance keeps in LDS besides the staged descriptors: the pixel positions of
+// the block's rows and of the staged columns, and one running bound per row.
+struct GeneralLds {
+    const double2 *ptsRow; // this wave's rows
+    const double2 *ptsCol; // the 32 columns of the step
+    unsigned *bound;       // this wave's rows: largest lower bound so far (ordered key, 0 = none)
+};
+
 // Candidate test of one 32-column step and the rare emission path.  colBase = first column of
 // the step.
 //
 // Strict instances (GENERAL = false) queue every cell above the bound; a slice that overflows
-// flags the pair, and the general instance then redoes the flagged pairs.  In the general
-// instance, once a wave has queued half its slice (loose thresholds, where most cells clear the
-// bound), and always for the dot metric, a cell is queued only if it can still be the best of its row or of its column: its upper bound must reach
-// the largest lower bound seen so far there (runMax, ordered keys, 0 = nothing yet).  The true
-// arg-max always passes: its upper bound is at least its exact value, which is at least every
-// other cell's exact value, which is at least that cell's lower bound.  Racing updates only make
-// the test more permissive.
+// flags the pair, and the general instance then redoes the flagged pairs (loose thresholds,
+// where most cells clear the bound; always for the dot metric).
+//
+// The general instance runs twice per pair, once with each image in the register-resident role.
+// A wave streams all columns past its rows in order, so "can this cell still be the best of its
+// row" is a running-maximum test that needs no communication outside the wave: a cell inside the
+// pixel gate is queued only if its upper bound reaches the largest lower bound seen so far in its
+// row.  The true arg-max of the row always passes: its upper bound is at least its exact value,
+// which is at least every other cell's exact value, which is at least that cell's lower bound;
+// cells outside the gate (match.cpp:45) never raise a bound.  Pass 0 thus queues every row best
+// and pass 1 every column best.  The bounds live in LDS and are raised with an atomic max whose
+// returned previous value decides the test, so the lanes that hold one row in the same step see
+// each other in some serial order.  localLo[idx] is a per-lane copy of the row's bound minus the
+// margin, in registers, so that most cells are rejected by a register compare; it only ever
+// trails the shared bound, which keeps the test permissive.
 template <typename AccT, bool DOT, bool GENERAL>
 __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
-                                             int colBase, int lane, float thr_m, WaveQueue &wq)
+                                             int colBase, int lane, float thr_m, WaveQueue &wq,
+                                             float (&localLo)[GENERAL ? AccT::NV : 1], const GeneralLds &gl)
 {
     constexpr int NV = AccT::NV;
-    bool hit = DOT;
-    if (!DOT) {
+    static_assert(NV <= 32, "one bit per accumulator value");
+    unsigned bits = 0;
+    if constexpr (!GENERAL) {
         // fmaxf ignores NaNs, and a NaN cell can never be accepted.  Four independent chains keep
         // the dependent-issue latency short; no branch, so the chain can be scheduled among MFMAs.
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = fmaxf(fmaxf(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
-        hit = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) > thr_m;
+        bits = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) > thr_m;
+    } else if (DOT) {
+        bits = 0xFFFFFFFFu;
+    } else {
+#pragma unroll
+        for (int idx = 0; idx < NV; idx++) {
+            const float v = acc.get(idx);
+            bits |= (unsigned)(v > thr_m && v >= localLo[idx]) << idx;
+        }
     }
-    if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) return;
 
     // rare path
     const int z = opaque_zero();
@@ -305,68 +331,74 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         return;
     }
 
-    if (!GENERAL || (!DOT && wq.n * 2 < wq.cap)) {
-        u64 bits = 0;
+    bool swapped = false;
+    if constexpr (!GENERAL) {
+        bits = 0;
 #pragma unroll
-        for (int idx = 0; idx < NV; idx++) bits |= (u64)(acc.get(idx) > thr_m) << idx;
-        while (__builtin_amdgcn_ballot_w64(bits != 0) != 0) {
-            const bool has = bits != 0;
-            const int bit = has ? __builtin_ctzll(bits) : 0;
-            bits &= bits - 1;
-            const int i = rowBase + AccT::row(bit, ln);
-            const int jj = colBase + AccT::col(bit, ln);
-            queue_push(wq, has && i < pr.nA && jj < pr.nB, i, jj, lane);
-        }
-        return;
-    }
-    if constexpr (!GENERAL) return;
-
-    const float thrp = fmaxf(g.threshold, 0.0f);
+        for (int idx = 0; idx < NV; idx++) bits |= (unsigned)(acc.get(idx) > thr_m) << idx;
+    } else {
+        const float thrp = fmaxf(g.threshold, 0.0f);
+        swapped = g.orient != 0;
+        unsigned takeBits = 0;
 #pragma unroll
-    for (int grp = 0; grp < AccT::NGROUP; grp++) {
-        const int jj = colBase + AccT::col(grp * AccT::GROUP, ln);
-        const bool colValid = jj < pr.nB;
-        const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
-        const double2 pb = g.pts[pr.rowB32 + (colValid ? jj : 0)];
-        unsigned *colSlot = g.runMax + pr.bestCol + (colValid ? jj : 0);
-        // agent-scope loads: other CUs' updates are in L2, this CU's vector L1 may hold an older line
-        const unsigned colKey0 = colValid ? __hip_atomic_load(colSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        unsigned colKey = colKey0;
+        for (int grp = 0; grp < AccT::NGROUP; grp++) {
+            constexpr unsigned groupMask = AccT::GROUP >= 32 ? 0xFFFFFFFFu : ((1u << AccT::GROUP) - 1u);
+            const int cj = AccT::col(grp * AccT::GROUP, ln);
+            const int jj = colBase + cj;
+            const bool colValid = jj < pr.nB;
+            const unsigned mine = colValid ? (bits >> (grp * AccT::GROUP)) & groupMask : 0u;
+            if (__builtin_amdgcn_ballot_w64(mine != 0) == 0) continue;
+            const float sB = (DOT && colValid) ? g.norms[pr.rowB32 + jj] : 1.0f;
+            const double2 pb = gl.ptsCol[cj];
+            unsigned prev[AccT::GROUP];
+            unsigned did = 0;
 #pragma unroll
-        for (int k = 0; k < AccT::GROUP; k++) {
-            const int idx = grp * AccT::GROUP + k;
-            const float v = acc.get(idx);
-            const int i = rowBase + AccT::row(idx, ln);
-            bool take = false;
-            if (colValid && i < pr.nA && (DOT || v > thr_m)) {
-                float lo = v - SIM_MARGIN, hi = v + SIM_MARGIN;
-                // A cell outside the pixel gate (match.cpp:45) is not part of any arg-max: it must
-                // neither be queued nor raise a running bound.
-                const double2 pa = g.pts[pr.rowA32 + i];
-                const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
-                bool cnd = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < (double)g.maxDistSq;
-                if (DOT) { // dot = approx * sA * sB within 1e-3 * sA * sB
-                    const float p = g.norms[pr.rowA32 + i] * sB;
-                    lo *= p;
-                    hi *= p;
-                    cnd = cnd && hi > thrp;
-                }
-                if (cnd) {
-                    unsigned *rowSlot = g.runMax + pr.bestRow + i;
-                    const unsigned rowKey = __hip_atomic_load(rowSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool rowOk = rowKey == 0 || hi >= ordered_value(rowKey);
-                    const bool colOk = colKey == 0 || hi >= ordered_value(colKey);
-                    if (rowOk || colOk) {
-                        const unsigned klo = ordered_key(lo);
-                        if (klo > rowKey) atomicMax(rowSlot, klo);
-                        colKey = max(colKey, klo);
-                        take = true;
+            for (int k = 0; k < AccT::GROUP; k++) {
+                const int idx = grp * AccT::GROUP + k;
+                const int ri = AccT::row(idx, ln);
+                prev[k] = 0;
+                if (((mine >> k) & 1u) && rowBase + ri < pr.nA) {
+                    float lo = acc.get(idx) - SIM_MARGIN;
+                    const double2 pa = gl.ptsRow[ri];
+                    const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
+                    bool cnd = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < (double)g.maxDistSq;
+                    if (DOT) { // dot = approx * sA * sB within 1e-3 * sA * sB
+                        const float p = g.norms[pr.rowA32 + rowBase + ri] * sB;
+                        lo *= p;
+                        cnd = cnd && (acc.get(idx) + SIM_MARGIN) * p > thrp;
+                    }
+                    if (cnd) {
+                        did |= 1u << k;
+                        prev[k] = atomicMax(&gl.bound[ri], ordered_key(lo));
                     }
                 }
             }
-            queue_push(wq, take, i, jj, lane);
+#pragma unroll
+            for (int k = 0; k < AccT::GROUP; k++) {
+                const int idx = grp * AccT::GROUP + k;
+                if ((did >> k) & 1u) {
+                    float lo = acc.get(idx) - SIM_MARGIN, hi = acc.get(idx) + SIM_MARGIN;
+                    if (DOT) {
+                        const float p = g.norms[pr.rowA32 + rowBase + AccT::row(idx, ln)] * sB;
+                        lo *= p;
+                        hi *= p;
+                    }
+                    const float rowLo = prev[k] ? ordered_value(prev[k]) : -INFINITY;
+                    if (hi >= rowLo) takeBits |= 1u << idx;
+                    // hi >= bound  <=>  v >= bound - margin (cosine; the dot metric has no local copy)
+                    if (!DOT) localLo[idx] = fmaxf(localLo[idx], fmaxf(lo, rowLo) - SIM_MARGIN);
+                }
+            }
         }
-        if (colKey > colKey0) atomicMax(colSlot, colKey);
+        bits = takeBits;
+    }
+    while (__builtin_amdgcn_ballot_w64(bits != 0) != 0) {
+        const bool has = bits != 0;
+        const int bit = has ? __builtin_ctz(bits) : 0;
+        bits &= bits - 1;
+        const int i = rowBase + AccT::row(bit, ln);
+        const int jj = colBase + AccT::col(bit, ln);
+        queue_push(wq, has && i < pr.nA && jj < pr.nB, swapped ? jj : i, swapped ? i : jj, lane);
     }
 }
 
@@ -403,12 +435,28 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     static_assert(BN_ * 256 % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
     static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers");
     __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * 256];
+    // general instance: positions of the block's rows, of the staged columns, and the row bounds
+    constexpr int BLOCK_ROWS = WAVES * RT * 32;
+    __shared__ double2 ptsRow[GENERAL ? BLOCK_ROWS : 1];
+    __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? BN_ : 1];
+    __shared__ unsigned rowBound[GENERAL ? BLOCK_ROWS : 1];
+    static_assert(!GENERAL || (STAGES == 2 && PIPE == 0), "the general instance is double buffered, not pipelined");
 
     static_assert(GENERAL || !DOT, "the dot metric needs the general instance");
     const int2 w = g.work[blockIdx.x];
     if (w.x < 0) return;
     if (g.onlyFlagged && g.pairOvf[w.x] != 1) return; // second pass: pairs the strict pass gave up on
-    const PairRec pr = g.pairs[w.x];
+    PairRec pr = g.pairs[w.x];
+    // slices of the pair's candidate list: one per wave of the strict pass, or one per wave of
+    // both orientations of the general pass
+    const int nQ0 = ((pr.nA + WAVES * RT * 32 - 1) / (WAVES * RT * 32)) * WAVES;
+    const int nQ1 = ((pr.nB + WAVES * RT * 32 - 1) / (WAVES * RT * 32)) * WAVES;
+    if (GENERAL && g.orient) { // image B's rows stay in registers, image A streams
+        const int n = pr.nA; pr.nA = pr.nB; pr.nB = n;
+        int64_t t = pr.rowA32; pr.rowA32 = pr.rowB32; pr.rowB32 = t;
+        t = pr.rowA16; pr.rowA16 = pr.rowB16; pr.rowB16 = t;
+        t = pr.bestRow; pr.bestRow = pr.bestCol; pr.bestCol = t;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -445,7 +493,22 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
 #pragma unroll
         for (int u = 0; u < DMA; u++)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + srcOff[u]), (lptr_t)&lds[buf][(wave * DMA + u) * 1024], 16, 0, 0);
+        if constexpr (GENERAL) { // the step's pixel positions, 64 columns per instruction (the table has no padding)
+            if (wave == 0) {
+#pragma unroll
+                for (int u = 0; u < BN_ / 64; u++) {
+                    const int j = min(c * BN_ + u * 64 + lane, pr.nB - 1);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g.pts + pr.rowB32 + j), (lptr_t)&ptsCol[buf & 1][u * 64], 16, 0, 0);
+                }
+            }
+        }
     };
+    if constexpr (GENERAL) {
+        for (int rr = tid; rr < BLOCK_ROWS; rr += WAVES * 64) {
+            ptsRow[rr] = g.pts[pr.rowA32 + min(w.y * BLOCK_ROWS + rr, pr.nA - 1)];
+            rowBound[rr] = 0;
+        }
+    }
     using AccT = typename std::conditional<MF16 != 0, Acc16<RT>, Acc32<RT>>::type;
     auto mfma_step = [&](AccT &acc, int buf, int sub) {
         acc.zero();
@@ -470,17 +533,24 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
         }
     };
     // this wave's slice of the pair's candidate list
-    const int nQueues = ((pr.nA + WAVES * RT * 32 - 1) / (WAVES * RT * 32)) * WAVES;
-    const int queueId = w.y * WAVES + wave;
+    const int nQueues = GENERAL ? nQ0 + nQ1 : nQ0;
+    const int queueId = ((GENERAL && g.orient) ? nQ0 : 0) + w.y * WAVES + wave;
+    float localLo[GENERAL ? AccT::NV : 1];
+#pragma unroll
+    for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
     WaveQueue wq;
     wq.cap = g.candCap / nQueues;
     wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
     wq.n = 0;
+    int buf = 0;
     auto test = [&](const AccT &acc, int colBase) {
         if constexpr ((ABL & 2) != 0)
             keep_alive<RT>(acc);
         else
-            sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, thr_m, wq);
+            sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, thr_m, wq, localLo,
+                                             GeneralLds{ptsRow + (GENERAL ? wave * RT * 32 : 0),
+                                                        &ptsCol[GENERAL ? buf & 1 : 0][GENERAL ? (colBase % BN_) : 0],
+                                                        rowBound + (GENERAL ? wave * RT * 32 : 0)});
     };
 
     AccT accA, accB;
@@ -496,7 +566,6 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
         __syncthreads();
     else if (nChunks > 1)
         dma_issue(1, 1);
-    int buf = 0;
     for (int c = 0; c < nChunks; c++) {
         if (STAGES == 2) {
             if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
@@ -510,6 +579,20 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
             __builtin_amdgcn_s_barrier();
             if (c + 2 < nChunks) dma_issue(c + 2, (buf == 0) ? 2 : buf - 1);
         }
+        if constexpr (GENERAL && !DOT) {
+            // Pull the shared row bounds into the per-lane copies: a lane learns of a bound raised by
+            // another lane's column only here or when one of its own cells gets past its stale copy.
+            // Bounds move often during the first columns and rarely later.
+            if (c < 8 || (c & 7) == 0) {
+#pragma unroll
+                for (int idx = 0; idx < AccT::NV; idx++) {
+                    const unsigned key = rowBound[wave * RT * 32 + AccT::row(idx, lane)];
+                    localLo[idx] = fmaxf(localLo[idx], (key ? ordered_value(key) : -INFINITY) - SIM_MARGIN);
+                }
+            }
+        }
+        // a strict wave whose slice has overflowed only keeps the staging going: the pair is redone anyway
+        if (GENERAL || PIPE || wq.n <= wq.cap)
 #pragma unroll
         for (int sub = 0; sub < NSUB; sub += 2) {
             const int j0 = c * BN_ + sub * 32;
@@ -552,8 +635,8 @@ struct SimVariant {
 };
 #define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES, MF16)                                              \
     {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, MF16, false>, \
-     match_sim_kernel<RT, WAVES, BN_, 2, 0, false, ABL, STAGES, MF16, true>,                                    \
-     match_sim_kernel<RT, WAVES, BN_, 2, 0, true, ABL, STAGES, MF16, true>,                                     \
+     match_sim_kernel<RT, WAVES, BN_, 2, 0, false, ABL, 2, MF16, true>,                                         \
+     match_sim_kernel<RT, WAVES, BN_, 2, 0, true, ABL, 2, MF16, true>,                                          \
      "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL "_st" #STAGES "_mf16" #MF16}
 static const SimVariant kSimVariants[] = {
     SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 0), // 0: 8 waves x 64 rows, one block per CU
@@ -575,6 +658,15 @@ static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVaria
 // ---------------------------------------------------------------------------------------
 // exact pass over the candidate lists
 // ---------------------------------------------------------------------------------------
+// Slices of a pair's candidate list as the similarity kernels laid them out: the strict pass
+// has one per wave over image A's rows, the general pass adds one per wave over image B's.
+__device__ __forceinline__ int pair_queues(const MatchArgs &g, const PairRec &pr, int p)
+{
+    const int nQ0 = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
+    const int nQ1 = ((pr.nB + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
+    return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0;
+}
+
 // One wave per candidate slice, four slices per block.
 __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
 {
@@ -584,7 +676,7 @@ __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= g.maxQueues) return;
     const PairRec pr = g.pairs[p];
-    const int nQueues = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
+    const int nQueues = pair_queues(g, pr, p);
     if (q >= nQueues) return;
     const int cap = g.candCap / nQueues;
     const int n = g.candCount[p * g.maxQueues + q];
@@ -612,7 +704,7 @@ __global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
     if (g.pairOvf[p] == 2) return; // match_exact_kernel scores the whole pair
     const PairRec pr = g.pairs[p];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nQueues = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
+    const int nQueues = pair_queues(g, pr, p);
     const int cap = g.candCap / nQueues;
 
     // exclusive prefix of the slice counts (nQueues <= 1024)
@@ -820,7 +912,7 @@ struct sfm_match_result {
     int n_pairs = 0;
     DevBuf offsets; // int64[n_pairs+1]
     DevBuf pairs;   // int2[sum min(nA,nB)]
-    DevBuf pairRecs, work, cand, candCount, pairOvf, best, runMax, ovfList, counts, stats, m1, m2;
+    DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2;
     PinBuf hostRecs, hostWork;
     int64_t total = -1;
 };
@@ -952,7 +1044,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
-                      &r->best, &r->runMax, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2};
+                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2};
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
@@ -993,16 +1085,21 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     // --- host records -------------------------------------------------------------------
     SFM_HIP(ctx, res->hostRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
     PairRec *recs = res->hostRecs.as<PairRec>();
-    int64_t outTotalCap = 0, maxBest = 0, maxWork = 0;
-    std::vector<int64_t> chunkWorkBase;
-    std::vector<int> chunkWorkCount;
+    int64_t outTotalCap = 0, maxBest = 0;
+    // work lists per chunk: [0] row blocks of image A (both passes), [1] row blocks of image B
+    // (the general pass in its second orientation)
+    std::vector<int64_t> chunkWorkBase[2];
+    std::vector<int> chunkWorkCount[2];
     int64_t workTotal = 0;
     int maxNA = 0, maxNB = 0;
     const int wavesPerBlock = variant.threads / 64;
+    auto row_blocks = [&](const PairRec &r, int orient) {
+        if (r.nA <= 0 || r.nB <= 0) return 0;
+        return ((orient ? r.nB : r.nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
+    };
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
         int64_t bestOff = 0;
-        int64_t queueLen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int p = c0; p < c1; p++) {
             const int ia = pair_list[2 * p], ib = pair_list[2 * p + 1];
             if (ia < 0 || ia >= set->n_images || ib < 0 || ib >= set->n_images)
@@ -1029,36 +1126,40 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             else
                 r.thr_m = (thrp == 0.0f) ? -SIM_MARGIN : 0.0f; // DOT with a positive bound tests per cell
             outTotalCap += std::min(A.n, B.n);
-            queueLen[(p - c0) & 7] += (B.n > 0) ? (A.n + BLOCK_ROWS - 1) / BLOCK_ROWS : 0;
             maxNA = std::max(maxNA, A.n);
             maxNB = std::max(maxNB, B.n);
         }
         maxBest = std::max(maxBest, bestOff);
-        int64_t qmax = 0;
-        for (int x = 0; x < 8; x++) qmax = std::max(qmax, queueLen[x]);
-        chunkWorkBase.push_back(workTotal);
-        chunkWorkCount.push_back((int)(qmax * 8));
-        workTotal += qmax * 8;
-        maxWork = std::max(maxWork, qmax * 8);
+        for (int o = 0; o < 2; o++) {
+            int64_t queueLen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int p = c0; p < c1; p++) queueLen[(p - c0) & 7] += row_blocks(recs[p], o);
+            int64_t qmax = 0;
+            for (int x = 0; x < 8; x++) qmax = std::max(qmax, queueLen[x]);
+            chunkWorkBase[o].push_back(workTotal);
+            chunkWorkCount[o].push_back((int)(qmax * 8));
+            workTotal += qmax * 8;
+        }
     }
 
     // Work list: block b of a chunk takes entry b.  Blocks b and b + 8 run on the same XCD
     // (round-robin dispatch), so every pair's row blocks are dealt to one residue class mod 8
-    // and share that XCD's L2 copy of image B.
+    // and share that XCD's L2 copy of the streamed image.
     SFM_HIP(ctx, res->hostWork.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
     int2 *work = res->hostWork.as<int2>();
     {
         size_t ci = 0;
         for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
             const int c1 = std::min(n_pairs, c0 + chunkPairs);
-            int2 *wl = work + chunkWorkBase[ci];
-            const int cnt = chunkWorkCount[ci];
-            for (int k = 0; k < cnt; k++) wl[k] = make_int2(-1, 0);
-            int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int p = c0; p < c1; p++) {
-                const int x = (p - c0) & 7;
-                const int nb = (recs[p].nB > 0) ? (recs[p].nA + BLOCK_ROWS - 1) / BLOCK_ROWS : 0;
-                for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb);
+            for (int o = 0; o < 2; o++) {
+                int2 *wl = work + chunkWorkBase[o][ci];
+                const int cnt = chunkWorkCount[o][ci];
+                for (int k = 0; k < cnt; k++) wl[k] = make_int2(-1, 0);
+                int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int p = c0; p < c1; p++) {
+                    const int x = (p - c0) & 7;
+                    const int nb = row_blocks(recs[p], o);
+                    for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb);
+                }
             }
         }
     }
@@ -1069,11 +1170,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, res->pairs.reserve((size_t)(outTotalCap ? outTotalCap : 1) * sizeof(int2)));
     SFM_HIP(ctx, res->cand.reserve((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)));
-    const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
+    const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
     SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * maxQueues * sizeof(int)));
     SFM_HIP(ctx, res->pairOvf.reserve((size_t)chunkPairs * sizeof(int)));
     SFM_HIP(ctx, res->best.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(u64)));
-    SFM_HIP(ctx, res->runMax.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(unsigned)));
     SFM_HIP(ctx, res->ovfList.reserve((size_t)(chunkPairs + 1) * sizeof(int)));
     SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
     SFM_HIP(ctx, res->stats.reserve(2 * sizeof(u64)));
@@ -1101,7 +1201,6 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.blockRows = BLOCK_ROWS;
     g.wavesPerBlock = wavesPerBlock;
     g.best = res->best.as<u64>();
-    g.runMax = res->runMax.as<unsigned>();
     g.ovfList = res->ovfList.as<int>();
     g.stats = res->stats.as<u64>();
     g.candCap = candCap;
@@ -1115,26 +1214,38 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
         const int np = c1 - c0;
         g.pairs = res->pairRecs.as<PairRec>() + c0;
-        g.work = res->work.as<int2>() + chunkWorkBase[ci];
+        const int2 *workList[2] = {res->work.as<int2>() + chunkWorkBase[0][ci], res->work.as<int2>() + chunkWorkBase[1][ci]};
+        g.work = workList[0];
+        g.orient = 0;
         int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
         if (bestLen > 0) {
             SFM_HIP(ctx, hipMemsetAsync(res->best.p, 0, (size_t)bestLen * sizeof(u64), st));
-            SFM_HIP(ctx, hipMemsetAsync(res->runMax.p, 0, (size_t)bestLen * sizeof(unsigned), st));
         }
         SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * maxQueues * sizeof(int), st));
         SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)np * sizeof(int), st));
-        const int nblk = chunkWorkCount[ci];
+        const int nblk = chunkWorkCount[0][ci];
         if (nblk > 0) {
-            SFM_HIP(ctx, sfm_span_begin(ctx, 0));
-            g.onlyFlagged = 0;
-            hipLaunchKernelGGL(metric == SFM_METRIC_COSINE ? variant.strict : variant.dot, dim3(nblk),
-                               dim3(variant.threads), 0, st, g);
-            SFM_HIP(ctx, sfm_span_end(ctx, 0));
-            if (metric == SFM_METRIC_COSINE) { // pairs whose slices overflowed: again, with the filter
-                g.onlyFlagged = 1;
-                hipLaunchKernelGGL(variant.general, dim3(nblk), dim3(variant.threads), 0, st, g);
+            const bool cosine = metric == SFM_METRIC_COSINE;
+            if (cosine) {
+                SFM_HIP(ctx, sfm_span_begin(ctx, 0));
                 g.onlyFlagged = 0;
+                hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(variant.threads), 0, st, g);
+                SFM_HIP(ctx, sfm_span_end(ctx, 0));
             }
+            // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
+            // orientations.  Dot: every pair takes this path.
+            g.onlyFlagged = cosine ? 1 : 0;
+            for (int o = 0; o < 2; o++) {
+                g.orient = o;
+                g.work = workList[o];
+                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0));
+                hipLaunchKernelGGL(cosine ? variant.general : variant.dot, dim3(chunkWorkCount[o][ci]),
+                                   dim3(variant.threads), 0, st, g);
+                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0));
+            }
+            g.onlyFlagged = 0;
+            g.orient = 0;
+            g.work = workList[0];
             if (candCap > 0) {
                 if (set->dim == 128 && maxQueues <= 1024)
                     hipLaunchKernelGGL(match_cand128_kernel, dim3(4, np), dim3(256), 0, st, g);
