@@ -8,6 +8,8 @@ from sfm_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
+DEFAULT_CAND_CAPACITY = 524288
+
 
 def check_pair(ctx, oracle, dA, pA, dB, pB, thr, gate=1e8, metric=0):
     got, g1, g2 = ctx.match_pair(dA, pA, dB, pB, threshold=thr, max_dist_sq=gate, metric=metric, return_best=True)
@@ -57,7 +59,7 @@ def test_candidate_list_overflow(ctx, oracle):
         ctx.set_option("cand_capacity", 0)
         check_pair(ctx, oracle, dA, pA, dB, pB, 0.2)
     finally:
-        ctx.set_option("cand_capacity", 32768)
+        ctx.set_option("cand_capacity", DEFAULT_CAND_CAPACITY)
 
 
 def test_ties_pick_lowest_index(ctx, oracle):
@@ -201,4 +203,33 @@ def test_loose_threshold_with_tight_pixel_gate(ctx, oracle, thr):
         for gate in (60.0 * 60.0, 300.0 * 300.0, 1500.0 * 1500.0):
             check_pair(ctx, oracle, dA, pA, dB, pB, thr, gate)
     finally:
-        ctx.set_option("cand_capacity", 32768)
+        ctx.set_option("cand_capacity", DEFAULT_CAND_CAPACITY)
+
+
+@pytest.mark.parametrize("nA,nB", [(700, 1300), (1300, 700), (64, 2000), (2000, 1), (1025, 1025)])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_second_pass_both_orientations(ctx, oracle, nA, nB, metric):
+    """Every cell clears the threshold, the list is too small for all of them but large enough for
+    the cells that can be a row best or a column best: the second pass (row-best filter, once with
+    each image as the row image) must deliver the reference's result without cell-by-cell scoring."""
+    n = max(nA, nB)
+    d, p, _ = synth.image_set(2, n, shared_frac=0.4, seed=53)
+    d = np.maximum(d, 15)
+    counts = np.array([nA, nB], np.int32)
+    desc = np.concatenate([d[:nA], d[n:n + nB]])
+    pts = np.concatenate([p[:nA], p[n:n + nB]])
+    ctx.set_option("cand_capacity", 65536)
+    try:
+        s = ctx.imageset(counts, desc, pts)
+        for gate in (1e8, 400.0 * 400.0):
+            res = s.match(np.array([[0, 1]], np.int32), threshold=0.0, max_dist_sq=gate, metric=metric)
+            exp, _, _ = oracle.match(desc[:nA], pts[:nA], desc[nA:], pts[nA:], threshold=0.0, max_dist_sq=gate,
+                                     metric=metric)
+            assert np.array_equal(res.pairs(), exp)
+            cand, cell_by_cell = res.stats()
+            assert cell_by_cell == 0
+            if nA * nB > 65536:
+                assert cand < nA * nB // 4, "the filter should have dropped most cells"
+        s.close()
+    finally:
+        ctx.set_option("cand_capacity", DEFAULT_CAND_CAPACITY)
