@@ -60,8 +60,13 @@ const char *sfm_last_error(const sfm_ctx *ctx);
 const char *sfm_version(void);
 
 /* Tunables (all optional).  key: "cand_capacity" (candidate slots per image
- * pair, default 32768), "pairs_per_launch" (default 2048),
- * "hyps_per_launch".  Returns SFM_ERR_INVALID_ARG for an unknown key. */
+ * pair, default 524288; pairs that need more are scored cell by cell),
+ * "pairs_per_launch" (default 2048), "hyps_per_launch", "sim_variant"
+ * (instance of the similarity kernel, 0 .. 12; 9 and above are timing-only
+ * ablations with wrong results), "ransac_filter" (1 = skip evaluations the
+ * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
+ * everything; results are identical).  Returns SFM_ERR_INVALID_ARG for an
+ * unknown key or a value out of range. */
 int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);
 
 /* Device time, in milliseconds, that the dominant kernel of the last batch
