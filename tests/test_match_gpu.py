@@ -233,3 +233,18 @@ def test_second_pass_both_orientations(ctx, oracle, nA, nB, metric):
         s.close()
     finally:
         ctx.set_option("cand_capacity", DEFAULT_CAND_CAPACITY)
+
+
+def test_32k_features_properties(ctx):
+    """32768 x 32768 (the largest configured image size): the image swap transposes the match set,
+    results are ascending and one-to-one, and nothing is scored cell by cell."""
+    d, p, c = synth.image_set(2, 32768, seed=78)
+    s = ctx.imageset(c, d, p)
+    res = s.match(np.array([[0, 1], [1, 0]], np.int32), threshold=0.95, max_dist_sq=100.0 * 100.0)
+    off, pairs = res.offsets(), res.pairs()
+    ab, ba = pairs[off[0]:off[1]], pairs[off[1]:off[2]]
+    assert len(ab) > 5000
+    assert np.all(np.diff(ab[:, 0]) > 0) and len(np.unique(ab[:, 1])) == len(ab)
+    assert set(map(tuple, ab)) == set(map(tuple, ba[:, ::-1]))
+    assert res.stats()[1] == 0
+    s.close()
