@@ -190,6 +190,36 @@ int sfm_ransac_batch_inlier_offsets(sfm_ransac_batch *b, int64_t *offsets_out /*
 int sfm_ransac_batch_inliers(sfm_ransac_batch *b, int32_t *inliers_out);
 void sfm_ransac_batch_destroy(sfm_ransac_batch *b);
 
+/* ---- matching -> RANSAC without leaving the device -------------------------
+ * Replaces the correspondence assembly of Scene::getApproximations,
+ * scene.cpp:216-252: for every match (i, j) of every pair of a match result,
+ * x = normalizePoints(pixel of A_i), y = normalizePoints(pixel of B_j)
+ * (scene.cpp:495-501: the first two components of Kinv * (u, v, 1); Kinv is the
+ * caller's K.inverse(), column-major), in match-list order, in the CSR layout
+ * of the batched RANSAC calls (offsets = the match result's offsets).
+ */
+typedef struct sfm_corr sfm_corr;
+int sfm_corr_from_matches(sfm_ctx *ctx, const sfm_imageset *set, sfm_match_result *res,
+                          const double *Kinv, sfm_corr **corr_inout);
+int sfm_corr_offsets(sfm_corr *c, int64_t *offsets_out /* n_pairs+1 */);
+int sfm_corr_device(sfm_corr *c, const double **x_device, const double **y_device);
+int sfm_corr_fetch(sfm_corr *c, double *x_out, double *y_out);
+/* Sample table samples[pair][n_hyp][8] drawn on the device (replaces the
+ * time-seeded shuffle of RANSAC.cpp:170,201 by a counter-based generator, so a
+ * run can be repeated): row h of pair p with n correspondences takes, for
+ * k = 0..7, position floor(r_k * (n - k) / 2^64) among the indices not taken
+ * yet, r_k = mix(s + (k + 1) * 0x9E3779B97F4A7C15), s = mix(seed ^ mix(p * 2^32 + h)),
+ * mix = the splitmix64 finaliser.  Pairs with fewer than 8 correspondences get
+ * rows of zeros.  samples_out (host, optional) receives a copy. */
+int sfm_corr_sample_table(sfm_corr *c, int n_hyp, uint64_t seed, const int32_t **samples_device,
+                          int32_t *samples_out);
+/* sfm_corr_sample_table + sfm_ransac_batch_run_device on the correspondences
+ * (scene.cpp:261 for every pair of the match result). */
+int sfm_ransac_batch_run_corr(sfm_ctx *ctx, sfm_corr *c, const double *K, int n_hyp, uint64_t seed,
+                              double max_squared_error, double success_prob, int adaptive, int loss,
+                              sfm_ransac_batch **batch_inout);
+void sfm_corr_destroy(sfm_corr *c);
+
 #ifdef __cplusplus
 }
 #endif

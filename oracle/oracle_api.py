@@ -60,6 +60,8 @@ def lib() -> C.CDLL:
                                     C.POINTER(C.c_int), _f64p, _i32p, _f64p, C.POINTER(C.c_int)]
     L.sfm_oracle_fit_hypotheses.argtypes = [_f64p, _f64p, _i32p, C.c_int, _f64p, _i32p]
     L.sfm_oracle_normalize_points.argtypes = [_f64p, _f64p, C.c_int, _f64p]
+    L.sfm_oracle_sample_table.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.c_int, _i32p]
+    L.sfm_oracle_sample_table.restype = None
     _lib = L
     return L
 
@@ -201,3 +203,10 @@ def normalize_points(K, pixels):
     lib().sfm_oracle_normalize_points(np.asfortranarray(Kinv).reshape(-1, order="F").copy(), pixels,
                                       len(pixels), out)
     return out
+
+
+def sample_table(n: int, n_hyp: int, seed: int, pair_index: int) -> np.ndarray:
+    """The device library's counter-based sample table for one pair (see include/sfm_amd.h)."""
+    out = np.zeros((max(n_hyp, 1), 8), np.int32)
+    lib().sfm_oracle_sample_table(int(n), int(n_hyp), int(seed), int(pair_index), out)
+    return out[:n_hyp]

@@ -903,3 +903,40 @@ void sfm_oracle_normalize_points(const double *Kinv, const double *pixels, int n
         out[2 * i + 1] = (Kinv[1] * u + Kinv[4] * v) + Kinv[7];
     }
 }
+
+/* The sample-table generator of the device library (no counterpart in the reference, whose
+ * shuffle is time-seeded, RANSAC.cpp:170,201): row h of pair p, n correspondences. */
+static uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void sfm_oracle_sample_table(int64_t n, int n_hyp, uint64_t seed, int pair_index, int32_t *out)
+{
+    for (int h = 0; h < n_hyp; h++) {
+        int32_t *row = out + (size_t)h * 8;
+        if (n < 8) {
+            for (int k = 0; k < 8; k++) row[k] = 0;
+            continue;
+        }
+        uint64_t s = mix64(seed ^ mix64(((uint64_t)pair_index << 32) | (uint64_t)(uint32_t)h));
+        for (int k = 0; k < 8; k++) {
+            uint64_t r = mix64(s + (uint64_t)(k + 1) * 0x9E3779B97F4A7C15ull);
+            int64_t v = (int64_t)(((unsigned __int128)r * (uint64_t)(n - k)) >> 64);
+            /* v-th index not taken yet: walk the taken ones in ascending order */
+            int32_t taken[8];
+            for (int t = 0; t < k; t++) taken[t] = row[t];
+            for (int a = 1; a < k; a++) { /* insertion sort */
+                int32_t key = taken[a];
+                int b = a - 1;
+                while (b >= 0 && taken[b] > key) { taken[b + 1] = taken[b]; b--; }
+                taken[b + 1] = key;
+            }
+            for (int t = 0; t < k; t++)
+                if (taken[t] <= v) v++;
+            row[k] = (int32_t)v;
+        }
+    }
+}

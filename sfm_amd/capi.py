@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = [
     "sfm_ransac_pair", "sfm_eight_point_fit", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
     "sfm_ransac_batch_destroy",
+    "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
+    "sfm_ransac_batch_run_corr", "sfm_corr_destroy",
 ]
 
 
@@ -89,6 +91,14 @@ def lib() -> C.CDLL:
     L.sfm_ransac_batch_inliers.argtypes = [vp, vp]
     L.sfm_ransac_batch_destroy.argtypes = [vp]
     L.sfm_ransac_batch_destroy.restype = None
+    L.sfm_corr_from_matches.argtypes = [vp, vp, vp, vp, P(vp)]
+    L.sfm_corr_offsets.argtypes = [vp, vp]
+    L.sfm_corr_device.argtypes = [vp, P(vp), P(vp)]
+    L.sfm_corr_fetch.argtypes = [vp, vp, vp]
+    L.sfm_corr_sample_table.argtypes = [vp, i32, C.c_uint64, P(vp), vp]
+    L.sfm_ransac_batch_run_corr.argtypes = [vp, vp, vp, i32, C.c_uint64, f64, f64, i32, i32, P(vp)]
+    L.sfm_corr_destroy.argtypes = [vp]
+    L.sfm_corr_destroy.restype = None
     _lib = L
     return L
 
@@ -340,6 +350,61 @@ class RansacBatch:
     def close(self):
         if self._h:
             lib().sfm_ransac_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Correspondences:
+    """Normalised correspondences of every pair of a match result, resident on the device
+    (sfm_corr_*): the hand-off from matching to RANSAC."""
+
+    def __init__(self, ctx: Context, imageset: ImageSet, result: MatchResult, K, reuse: "Correspondences" = None):
+        self.ctx = ctx
+        self._h = reuse._h if reuse is not None else C.c_void_p()
+        if reuse is not None:
+            reuse._h = C.c_void_p()
+        Kinv = np.linalg.inv(np.asarray(K, np.float64))
+        self.Kinv = Kinv
+        Kc = np.asfortranarray(Kinv).reshape(-1, order="F").copy()
+        ctx.check(lib().sfm_corr_from_matches(ctx._h, imageset._h, result._h, _ptr(Kc), C.byref(self._h)))
+        self.n_pairs = result.n_pairs
+
+    def offsets(self) -> np.ndarray:
+        off = np.zeros(self.n_pairs + 1, np.int64)
+        self.ctx.check(lib().sfm_corr_offsets(self._h, _ptr(off)))
+        return off
+
+    def fetch(self):
+        n = int(self.offsets()[-1])
+        x = np.zeros((max(n, 1), 2))
+        y = np.zeros((max(n, 1), 2))
+        self.ctx.check(lib().sfm_corr_fetch(self._h, _ptr(x), _ptr(y)))
+        return x[:n], y[:n]
+
+    def sample_table(self, n_hyp: int, seed: int) -> np.ndarray:
+        out = np.zeros((max(self.n_pairs, 1), max(n_hyp, 1), 8), np.int32)
+        dev = C.c_void_p()
+        self.ctx.check(lib().sfm_corr_sample_table(self._h, n_hyp, C.c_uint64(seed), C.byref(dev), _ptr(out)))
+        return out[:self.n_pairs, :n_hyp]
+
+    def ransac(self, K, n_hyp: int, seed: int, max_sq_err=10.0, success_prob=0.99, adaptive=False,
+               loss=LOSS_REPROJECTION, batch: "RansacBatch" = None) -> "RansacBatch":
+        Kc = np.asfortranarray(K, np.float64).reshape(-1, order="F").copy()
+        b = batch if batch is not None else RansacBatch(self.ctx)
+        self.ctx.check(lib().sfm_ransac_batch_run_corr(self.ctx._h, self._h, _ptr(Kc), n_hyp, C.c_uint64(seed),
+                                                       max_sq_err, success_prob, int(bool(adaptive)), loss,
+                                                       C.byref(b._h)))
+        b.n_pairs = self.n_pairs
+        return b
+
+    def close(self):
+        if self._h:
+            lib().sfm_corr_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -10,11 +10,13 @@
 // How: the N x M similarity matrix is never stored.
 //   1. ingest (once per image set): per descriptor the fp32 squared norm in the reference's
 //      summation order and its sqrtf; an fp16 copy of the descriptor divided by that norm.
-//   2. match_sim_kernel: fp16 MFMA (v_mfma_f32_32x32x16_f16) over LDS-staged tiles gives an
-//      approximation of the cosine of every cell, good to 1.0e-3 absolute.  A cell whose
-//      approximation clears max(threshold, 0) - 1.5e-3 is a *candidate*; its (i, j) goes to
-//      the pair's candidate list.  Nothing else leaves the kernel.
-//   3. match_cand_kernel: every candidate is re-evaluated exactly as the reference does it
+//   2. match_sim_kernel: fp16 MFMA over LDS-staged tiles gives an approximation of the cosine
+//      of every cell, good to 1.0e-3 absolute.  A cell whose approximation clears
+//      max(threshold, 0) - 1.5e-3 is a *candidate*; its (i, j) goes to the pair's candidate
+//      list.  Nothing else leaves the kernel.  Pairs with more candidates than the list holds
+//      are redone with a filter that keeps only cells that can be a row or column best, and
+//      as a last resort scored cell by cell.
+//   3. match_cand128_kernel / match_cand_kernel: every candidate is re-evaluated exactly as the reference does it
 //      (128 sequential fp32 multiply-adds without contraction, IEEE sqrt/divide, fp64 pixel
 //      gate) and folded into per-row / per-column 64-bit keys (sim bits : ~index) with
 //      atomicMax, which is the reference's arg-max including its lowest-index tie rule.
@@ -22,7 +24,7 @@
 // Since every cell that the reference could accept is a candidate, and candidates are
 // scored with the reference's own arithmetic, the result is bit-identical to the
 // reference's for any finite input, not only for integer-valued SIFT descriptors.
-#include "common.h"
+#include "match_types.h"
 
 #include <type_traits>
 
@@ -40,15 +42,6 @@ typedef unsigned long long u64;
 // flags per image
 #define IMG_WILD_COS 1 // a descriptor norm outside [1e-12, 1e12] (and not 0/inf/nan)
 #define IMG_WILD_DOT 2 // a descriptor norm that is 0, non-finite or outside that range
-
-struct PairRec {
-    int32_t nA, nB;
-    int64_t rowA32, rowB32; // first row in desc32 / norms / pts
-    int64_t rowA16, rowB16; // first row in desc16
-    int64_t bestRow, bestCol; // first slot in the best[] array of the chunk
-    float thr_m;            // candidate bound on the approximate cosine
-    int32_t chunkLocal;     // index inside the chunk
-};
 
 struct MatchArgs {
     const _Float16 *desc16;
@@ -78,13 +71,6 @@ struct MatchArgs {
 // ---------------------------------------------------------------------------------------
 // ingest
 // ---------------------------------------------------------------------------------------
-struct ImageRec {
-    int32_t n;
-    int32_t pad;
-    int64_t row32;
-    int64_t row16;
-};
-
 // One thread per descriptor: normA += a[i]*a[i] in index order, no contraction
 // (match.hpp:38-43), then sqrtf.
 __global__ void ingest_norm_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
@@ -896,27 +882,6 @@ __global__ __launch_bounds__(1024) void match_scan_kernel(const int *__restrict_
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-struct sfm_imageset {
-    sfm_ctx *ctx = nullptr;
-    int n_images = 0;
-    int dim = 0;
-    std::vector<ImageRec> images;
-    std::vector<int> flags;
-    int64_t rows32 = 0, rows16 = 0;
-    DevBuf desc32, desc16, norms, pts, imageRecs, imageFlags;
-    bool owns_desc32 = true, owns_pts = true;
-};
-
-struct sfm_match_result {
-    sfm_ctx *ctx = nullptr;
-    int n_pairs = 0;
-    DevBuf offsets; // int64[n_pairs+1]
-    DevBuf pairs;   // int2[sum min(nA,nB)]
-    DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2;
-    PinBuf hostRecs, hostWork;
-    int64_t total = -1;
-};
-
 extern "C" void sfm_imageset_destroy(sfm_imageset *s)
 {
     if (!s) return;

@@ -146,3 +146,43 @@ def sample_table(n_corr: int, n_hyp: int, seed: int = 11, k: int = 8) -> np.ndar
         if not bad.any():
             return out.astype(np.int32)
         out[bad] = rng.integers(0, n_corr, size=(int(bad.sum()), k))
+
+
+def frame_sequence(n_frames: int, n_feat: int, carry: float = 0.6, seed: int = 2024, K=None, noise_px: float = 0.3,
+                   step: float = 0.08, rot_deg: float = 0.4):
+    """A camera moving past a static cloud: n_frames images of n_feat features, about carry*n_feat of
+    them re-detections of scene points that are also visible in the neighbouring frames (pixel shift
+    between neighbours well under 100 px), the rest clutter unique to the frame.  Stand-in for the
+    reference's default run (27 frames, consecutive pairs).
+    Returns (desc, pts, counts, poses) with poses[k] = (R, T) world -> camera k."""
+    K = default_K() if K is None else np.asarray(K, np.float64)
+    Kinv = np.linalg.inv(K)
+    rng = _rng(seed)
+    n_scene = int(n_feat * carry * 1.6)
+    # scene points in the frustum of the middle camera, depths 4..10
+    u = np.stack([rng.uniform(-400, IMAGE_W + 400, n_scene), rng.uniform(-300, IMAGE_H + 300, n_scene),
+                  np.ones(n_scene)], axis=1)
+    X = (u @ Kinv.T) * rng.uniform(4.0, 10.0, n_scene)[:, None]
+    scene_desc = sift_like(rng, n_scene)
+    axis = np.array([0.1, 1.0, 0.05])
+    descs, ptss, poses = [], [], []
+    for k in range(n_frames):
+        t = k - (n_frames - 1) / 2
+        R = _rodrigues(axis, np.deg2rad(rot_deg * t))
+        T = np.array([-step * t, 0.01 * t, 0.02 * t])
+        poses.append((R, T))
+        r = _rng([seed, k + 1])
+        Xc = X @ R.T + T
+        p = (Xc / Xc[:, 2:3]) @ K.T
+        vis = (Xc[:, 2] > 0.5) & (p[:, 0] >= 0) & (p[:, 0] < IMAGE_W) & (p[:, 1] >= 0) & (p[:, 1] < IMAGE_H)
+        idx = np.flatnonzero(vis)
+        keep = idx[r.random(len(idx)) < 0.9][: int(n_feat * carry)]  # detection misses some
+        n_clutter = n_feat - len(keep)
+        d = np.concatenate([perturb_sift(r, scene_desc[keep]), sift_like(r, n_clutter)])
+        q = np.concatenate([p[keep, :2] + noise_px * r.standard_normal((len(keep), 2)),
+                            np.stack([r.uniform(0, IMAGE_W, n_clutter), r.uniform(0, IMAGE_H, n_clutter)], axis=1)])
+        perm = r.permutation(n_feat)
+        descs.append(d[perm])
+        ptss.append(q[perm])
+    return (np.concatenate(descs).astype(np.float32), np.concatenate(ptss).astype(np.float64),
+            np.full(n_frames, n_feat, np.int32), poses)

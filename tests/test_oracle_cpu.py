@@ -248,3 +248,21 @@ def test_normalize_points(oracle):
     px = np.array([[2000.0, 1500.0], [0.0, 0.0], [3999.0, 17.5]])
     got = oracle.normalize_points(K, px)
     assert np.allclose(got, (px - [2000, 1500]) / 3000.0, atol=1e-15)
+
+
+def test_sample_table_generator(oracle):
+    """Rows are 8 distinct indices of range(n); different pairs and seeds give different tables; the
+    draw is uniform (every index equally likely in every column, chi-square at 5 sigma)."""
+    n, H = 50, 20000
+    t = oracle.sample_table(n, H, 123, 0)
+    srt = np.sort(t, axis=1)
+    assert t.min() >= 0 and t.max() < n and np.all(srt[:, 1:] != srt[:, :-1])
+    assert not np.array_equal(t, oracle.sample_table(n, H, 123, 1))
+    assert not np.array_equal(t, oracle.sample_table(n, H, 124, 0))
+    assert np.array_equal(t, oracle.sample_table(n, H, 123, 0))
+    for col in range(8):
+        hist = np.bincount(t[:, col], minlength=n)
+        chi2 = ((hist - H / n) ** 2 / (H / n)).sum()
+        assert chi2 < (n - 1) + 5 * np.sqrt(2 * (n - 1))
+    assert np.array_equal(np.sort(oracle.sample_table(8, 10, 1, 0), axis=1), np.tile(np.arange(8), (10, 1)))
+    assert not oracle.sample_table(7, 10, 1, 0).any()
