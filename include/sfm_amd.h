@@ -167,6 +167,12 @@ int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, int n, const
 int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n,
                         const int32_t *samples, int n_hyp, double *pose12_out);
 
+/* eightPointAlgorithm(points1, points2), eightPoint.cpp:57-223, on one point
+ * set: pose16_out = column-major [R|T; 0 0 0 1], points_out[n][3] (either may be
+ * NULL).  n < 8 -> SFM_ERR_INVALID_ARG with the reference's message. */
+int sfm_eight_point_algorithm(sfm_ctx *ctx, const double *x, const double *y, int n,
+                              double *pose16_out, double *points_out);
+
 /* ---- RANSAC: batch over many pairs ------------------------------------------
  * CSR correspondences: pair p owns x[2*off[p] .. 2*off[p+1]) (same for y);
  * samples[p][n_hyp][8] index into the pair's own range.  All pairs share K and
@@ -188,6 +194,18 @@ int sfm_ransac_batch_best(sfm_ransac_batch *b, int32_t *best_hyp_out, int32_t *b
                           double *best_toterr_out, double *pose12_out, int32_t *iterations_out);
 int sfm_ransac_batch_inlier_offsets(sfm_ransac_batch *b, int64_t *offsets_out /* n_pairs+1 */);
 int sfm_ransac_batch_inliers(sfm_ransac_batch *b, int32_t *inliers_out);
+/* Refit on the winner's inliers: eightPointAlgorithm(inliers1, inliers2),
+ * eightPoint.cpp:57-223, as Scene::getApproximations calls it after RANSAC
+ * (scene.cpp:264-298): the point set of a pair is its inlier list when that has
+ * at least 8 entries, else all its correspondences, else nothing (used = 0,
+ * pose = identity).  The correspondences of the RANSAC call must still be alive
+ * when this runs (device variants read the caller's memory).
+ * fetch: pose16_out[n_pairs][16] column-major [R|T; 0 0 0 1]; used_out[n_pairs];
+ * points_out[total][3] with pair p's used[p] triangulated points starting at
+ * row corr_offsets[p].  Any output may be NULL. */
+int sfm_ransac_batch_refit(sfm_ransac_batch *b);
+int sfm_ransac_batch_refit_fetch(sfm_ransac_batch *b, double *pose16_out, int32_t *used_out,
+                                 double *points_out);
 void sfm_ransac_batch_destroy(sfm_ransac_batch *b);
 
 /* ---- matching -> RANSAC without leaving the device -------------------------

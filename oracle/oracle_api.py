@@ -122,6 +122,11 @@ def eight_point_from_subset(calc1, calc2, all1, all2):
     return pose.reshape(4, 4, order="F").copy(), pts[:len(all1)].copy(), idx, counts
 
 
+def eight_point(points1, points2):
+    """eightPointAlgorithm(points1, points2) (eightPoint.cpp:57-223): pose (4x4), points, candidate, counts."""
+    return eight_point_from_subset(points1, points2, points1, points2)
+
+
 def loss(K, obs1, obs2, pt, pose, kind=LOSS_REPROJECTION) -> float:
     K = np.asfortranarray(K, np.float64)
     pose = np.asfortranarray(pose, np.float64)

@@ -29,9 +29,9 @@ EXPORTED_SYMBOLS = [
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats",
     "sfm_match_result_destroy",
-    "sfm_ransac_pair", "sfm_eight_point_fit", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
+    "sfm_ransac_pair", "sfm_eight_point_fit", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
-    "sfm_ransac_batch_destroy",
+    "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy",
 ]
@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
     L.sfm_ransac_pair.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, f64, f64, i32, i32, vp, i32, P(i32),
                                   P(i32), vp, vp, vp, P(i32)]
     L.sfm_eight_point_fit.argtypes = [vp, vp, vp, i32, vp, i32, vp]
+    L.sfm_eight_point_algorithm.argtypes = [vp, vp, vp, i32, vp, vp]
     L.sfm_ransac_batch_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
     L.sfm_ransac_batch_run_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
     L.sfm_ransac_batch_best.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -91,6 +92,8 @@ def lib() -> C.CDLL:
     L.sfm_ransac_batch_inliers.argtypes = [vp, vp]
     L.sfm_ransac_batch_destroy.argtypes = [vp]
     L.sfm_ransac_batch_destroy.restype = None
+    L.sfm_ransac_batch_refit.argtypes = [vp]
+    L.sfm_ransac_batch_refit_fetch.argtypes = [vp, vp, vp, vp]
     L.sfm_corr_from_matches.argtypes = [vp, vp, vp, vp, P(vp)]
     L.sfm_corr_offsets.argtypes = [vp, vp]
     L.sfm_corr_device.argtypes = [vp, P(vp), P(vp)]
@@ -207,6 +210,15 @@ class Context:
         pose12 = np.zeros((max(H, 1), 12))
         self.check(lib().sfm_eight_point_fit(self._h, _ptr(x), _ptr(y), len(x), _ptr(samples), H, _ptr(pose12)))
         return pose12[:H]
+
+    def eight_point_algorithm(self, x, y):
+        """eightPointAlgorithm (eightPoint.cpp:57-223): (pose 4x4, points [n,3])."""
+        x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
+        y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
+        pose = np.zeros(16)
+        pts = np.zeros((max(len(x), 1), 3))
+        self.check(lib().sfm_eight_point_algorithm(self._h, _ptr(x), _ptr(y), len(x), _ptr(pose), _ptr(pts)))
+        return pose.reshape(4, 4, order="F").copy(), pts[:len(x)]
 
     def ransac_batch(self, corr_offsets, x, y, K, samples, n_hyp, max_sq_err=10.0, success_prob=0.99,
                      adaptive=False, loss=LOSS_REPROJECTION, batch=None, device_ptrs=None):
@@ -346,6 +358,19 @@ class RansacBatch:
         out = np.zeros(max(int(off[-1]), 1), np.int32)
         self.ctx.check(lib().sfm_ransac_batch_inliers(self._h, _ptr(out)))
         return off, out[:int(off[-1])]
+
+    def refit(self, total: int):
+        """eightPointAlgorithm on every pair's inliers (all points when fewer than 8 inliers).
+        total = number of correspondences of the batch.  Returns (pose16 [P,4,4], used [P],
+        points [total,3]; pair p's points start at its correspondence offset)."""
+        self.ctx.check(lib().sfm_ransac_batch_refit(self._h))
+        P = max(self.n_pairs, 1)
+        pose = np.zeros((P, 16))
+        used = np.zeros(P, np.int32)
+        pts = np.zeros((max(total, 1), 3))
+        self.ctx.check(lib().sfm_ransac_batch_refit_fetch(self._h, _ptr(pose), _ptr(used), _ptr(pts)))
+        n = self.n_pairs
+        return pose[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy(), used[:n], pts[:total]
 
     def close(self):
         if self._h:

@@ -664,6 +664,232 @@ __global__ __launch_bounds__(1024) void ransac_scan_kernel(const int *__restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// refit on the inliers: eightPointAlgorithm(points1, points2), eightPoint.cpp:57-223
+// ---------------------------------------------------------------------------------------
+// One block per pair.  The point set is the winner's inlier list when it has at least 8 entries,
+// otherwise all correspondences of the pair (scene.cpp:264-298), otherwise nothing.
+//   1. The smallest right singular vector of the n x 9 matrix A (eightPoint.cpp:66-86) is the
+//      eigenvector of the smallest eigenvalue of A^T A: the 45 sums are reduced over the block in a
+//      fixed tree order, then a cyclic Jacobi eigen-iteration runs on the 9 x 9 matrix in LDS
+//      (threads 0..8 own one row / column element each per rotation).
+//   2. Thread 0: essential matrix -> 3x3 SVD -> the four (R, T) candidates (eightPoint.cpp:88-128).
+//   3. All threads: cheirality vote over all n points, first strict maximum (eightPoint.cpp:130-181).
+//   4. All threads: triangulation of all n points with the float cast of lambda (eightPoint.cpp:189-220).
+struct RefitArgs {
+    double *pose16; // [P][16] column-major 4x4
+    int *used;      // [P] points used (0: fewer than 8 correspondences, pose = identity)
+    double *points; // [total][3]; pair p at corrOff[p]
+};
+
+__global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, const RefitArgs rf)
+{
+    __shared__ double red[4][45];
+    __shared__ double M[9][9], V[9][9];
+    __shared__ double rot[2]; // c, s of the current rotation (s = 0: skip)
+    __shared__ int anyRot;
+    __shared__ double cand[2][9], T12s[3];
+    __shared__ int cnt4[4][4];
+    __shared__ int chosen;
+
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = g.corrOff[p];
+    const int nAll = (int)(g.corrOff[p + 1] - base);
+    const int nInl = g.inlCount[p];
+    const bool useInl = nInl >= 8;
+    const int n = useInl ? nInl : nAll;
+    const int32_t *list = g.inliers + g.inlOff[p];
+    double *pose = rf.pose16 + (size_t)p * 16;
+    if (n < 8) {
+        if (tid < 16) pose[tid] = ((tid & 3) == (tid >> 2)) ? 1.0 : 0.0;
+        if (tid == 0) rf.used[p] = 0;
+        return;
+    }
+
+    // 1. A^T A
+    double acc[45];
+#pragma unroll
+    for (int e = 0; e < 45; e++) acc[e] = 0.0;
+    for (int k = tid; k < n; k += 256) {
+        const int64_t at = base + (useInl ? list[k] : k);
+        const double2 a = g.x[at], b = g.y[at];
+        const double r[9] = {a.x * b.x, a.y * b.x, b.x, a.x * b.y, a.y * b.y, b.y, a.x, a.y, 1.0};
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = i; j < 9; j++) acc[e++] += r[i] * r[j];
+    }
+#pragma unroll
+    for (int e = 0; e < 45; e++) {
+        double v = acc[e];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+        if (lane == 0) red[wave][e] = v;
+    }
+    __syncthreads();
+    if (tid < 81) {
+        const int i = tid / 9, j = tid % 9;
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        const int e = a * 9 - a * (a - 1) / 2 + (b - a);
+        M[i][j] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    // cyclic Jacobi: M <- J^T M J, V <- V J until no off-diagonal element matters
+    for (int sweep = 0; sweep < 40; sweep++) {
+        if (tid == 0) anyRot = 0;
+        __syncthreads();
+        for (int pp = 0; pp < 8; pp++) {
+            for (int qq = pp + 1; qq < 9; qq++) {
+                if (tid == 0) {
+                    const double apq = M[pp][qq], app = M[pp][pp], aqq = M[qq][qq];
+                    double c = 1.0, sn = 0.0;
+                    if (apq != 0.0 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * c;
+                        anyRot = 1;
+                    }
+                    rot[0] = c;
+                    rot[1] = sn;
+                }
+                __syncthreads();
+                const double c = rot[0], sn = rot[1];
+                if (sn != 0.0) {
+                    double mp = 0, mq = 0, vp = 0, vq = 0;
+                    if (tid < 9) { // columns pp, qq of M and V, element tid
+                        mp = M[tid][pp];
+                        mq = M[tid][qq];
+                        vp = V[tid][pp];
+                        vq = V[tid][qq];
+                        M[tid][pp] = c * mp - sn * mq;
+                        M[tid][qq] = sn * mp + c * mq;
+                        V[tid][pp] = c * vp - sn * vq;
+                        V[tid][qq] = sn * vp + c * vq;
+                    }
+                    __syncthreads();
+                    if (tid < 9) { // rows pp, qq of M, element tid
+                        mp = M[pp][tid];
+                        mq = M[qq][tid];
+                        M[pp][tid] = c * mp - sn * mq;
+                        M[qq][tid] = sn * mp + c * mq;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const int again = anyRot; // written before the last barrier of the sweep
+        __syncthreads();          // everyone has read it before thread 0 clears it again
+        if (!again) break;
+    }
+
+    // 2. candidates
+    if (tid == 0) {
+        int best = 0;
+        for (int j = 1; j < 9; j++)
+            if (M[j][j] < M[best][best]) best = j;
+        double q[9];
+        for (int i = 0; i < 9; i++) q[i] = V[i][best];
+        const double E[3][3] = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}, {q[6], q[7], q[8]}};
+        double U[3][3], S[3], W[3][3];
+        svd3(E, U, S, W);
+        double R1[3][3], R2[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                const double w = U[i][2] * W[j][2];
+                R1[i][j] = (U[i][1] * W[j][0] - U[i][0] * W[j][1]) + w;
+                R2[i][j] = (U[i][0] * W[j][1] - U[i][1] * W[j][0]) + w;
+            }
+        const double s1 = det3(R1) < 0 ? -1.0 : 1.0, s2 = det3(R2) < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) {
+                cand[0][3 * i + j] = s1 * R1[i][j];
+                cand[1][3 * i + j] = s2 * R2[i][j];
+            }
+            T12s[i] = U[i][2];
+        }
+    }
+    __syncthreads();
+
+    // 3. cheirality vote
+    double Rc[2][3][3], T12[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            Rc[0][i][j] = cand[0][3 * i + j];
+            Rc[1][i][j] = cand[1][3 * i + j];
+        }
+        T12[i] = T12s[i];
+    }
+    int cnt[4] = {0, 0, 0, 0};
+    for (int k = tid; k < n; k += 256) {
+        const int64_t at = base + (useInl ? list[k] : k);
+        const double2 a = g.x[at], b = g.y[at];
+        const double bb = (b.x * b.x + b.y * b.y) + 1.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double sgn = (c & 1) ? -1.0 : 1.0;
+            const double Tc[3] = {sgn * T12[0], sgn * T12[1], sgn * T12[2]};
+            double av[3];
+            rot_apply_h(Rc[c >> 1], a.x, a.y, av);
+            double l0, l1;
+            triangulate_lambdas(av, b.x, b.y, bb, Tc, l0, l1);
+            if (l0 > 0 && l1 > 0) cnt[c]++;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int v = cnt[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+        if (lane == 0) cnt4[wave][c] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int maxIndex = 0, maxPoints = 0;
+        for (int c = 0; c < 4; c++) {
+            const int v = cnt4[0][c] + cnt4[1][c] + cnt4[2][c] + cnt4[3][c];
+            if (v > maxPoints) {
+                maxIndex = c;
+                maxPoints = v;
+            }
+        }
+        chosen = maxIndex;
+        rf.used[p] = n;
+    }
+    __syncthreads();
+    const int ci = chosen;
+    const double sgn = (ci & 1) ? -1.0 : 1.0;
+    const double Tc[3] = {sgn * T12[0], sgn * T12[1], sgn * T12[2]};
+    if (tid < 16) { // column-major [R | T; 0 0 0 1]
+        const int r = tid & 3, c = tid >> 2;
+        double v = (r == c) ? 1.0 : 0.0;
+        if (r < 3 && c < 3) v = cand[ci >> 1][3 * r + c];
+        if (r < 3 && c == 3) v = Tc[r];
+        pose[tid] = v;
+    }
+
+    // 4. triangulate
+    double *pts = rf.points + (size_t)base * 3;
+    for (int k = tid; k < n; k += 256) {
+        const int64_t at = base + (useInl ? list[k] : k);
+        const double2 a = g.x[at], b = g.y[at];
+        const double bb = (b.x * b.x + b.y * b.y) + 1.0;
+        double av[3];
+        rot_apply_h(Rc[ci >> 1], a.x, a.y, av);
+        double l0, l1;
+        triangulate_lambdas(av, b.x, b.y, bb, Tc, l0, l1);
+        const double lam = (double)(float)l0; // eightPoint.cpp:216
+        pts[3 * k + 0] = lam * a.x;
+        pts[3 * k + 1] = lam * a.y;
+        pts[3 * k + 2] = lam;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 struct sfm_ransac_batch {
@@ -672,7 +898,9 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers;
+        inlOff, inliers, refitPose, refitUsed, refitPoints;
+    RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
+    bool scored = false;   // the last run went through selection (not fit-only)
 };
 
 extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
@@ -681,7 +909,8 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
-                      &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers};
+                      &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
+                      &b->refitPose, &b->refitUsed, &b->refitPoints};
     for (DevBuf *d : bufs) d->release();
     delete b;
 }
@@ -722,6 +951,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     b->n_pairs = n_pairs;
     b->H = n_hyp;
     b->total = total;
+    b->scored = false;
     sfm_span_reset(ctx, 1);
     hipStream_t st = ctx->stream;
     const size_t PH = (size_t)(n_pairs ? n_pairs : 1) * (size_t)(n_hyp ? n_hyp : 1);
@@ -821,6 +1051,47 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         hipLaunchKernelGGL((ransac_inlier_kernel<true>), dim3(n_pairs), dim3(256), 0, st, g);
     }
     SFM_HIP(ctx, hipGetLastError());
+    b->args = g;
+    b->scored = !fit_only;
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_batch_refit(sfm_ransac_batch *b)
+{
+    if (!b) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    if (!b->scored) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "refit: the batch holds no RANSAC result");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P1 = (size_t)(b->n_pairs ? b->n_pairs : 1);
+    SFM_HIP(ctx, b->refitPose.reserve(P1 * 16 * sizeof(double)));
+    SFM_HIP(ctx, b->refitUsed.reserve(P1 * sizeof(int)));
+    SFM_HIP(ctx, b->refitPoints.reserve((size_t)(b->total ? b->total : 1) * 3 * sizeof(double)));
+    if (b->n_pairs == 0) return SFM_OK;
+    RefitArgs rf;
+    rf.pose16 = b->refitPose.as<double>();
+    rf.used = b->refitUsed.as<int>();
+    rf.points = b->refitPoints.as<double>();
+    hipLaunchKernelGGL(ransac_refit_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->args, rf);
+    SFM_HIP(ctx, hipGetLastError());
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_batch_refit_fetch(sfm_ransac_batch *b, double *pose16_out, int32_t *used_out,
+                                            double *points_out)
+{
+    if (!b) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    if (!b->refitPose.p) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "refit: sfm_ransac_batch_refit has not run");
+    if (b->n_pairs == 0) return SFM_OK;
+    const size_t P = (size_t)b->n_pairs;
+    if (pose16_out)
+        SFM_HIP(ctx, hipMemcpyAsync(pose16_out, b->refitPose.p, P * 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (used_out)
+        SFM_HIP(ctx, hipMemcpyAsync(used_out, b->refitUsed.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (points_out && b->total > 0)
+        SFM_HIP(ctx, hipMemcpyAsync(points_out, b->refitPoints.p, (size_t)b->total * 3 * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SFM_OK;
 }
 
@@ -980,6 +1251,25 @@ extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *
             rc = SFM_ERR_HIP;
         }
     }
+    sfm_ransac_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int sfm_eight_point_algorithm(sfm_ctx *ctx, const double *x, const double *y, int n, double *pose16_out,
+                                         double *points_out)
+{
+    if (!ctx) return SFM_ERR_INVALID_ARG;
+    if (n < 8) // eightPoint.cpp:59-62
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG,
+                 "EightPointAlgorithm: There have to be at least 8 pair-to-pair-correspondences (was: %d) to approximate a pose.", n);
+    if (!x || !y) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "EightPointAlgorithm: null input");
+    const int64_t off[2] = {0, n};
+    const double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    sfm_ransac_batch *b = nullptr;
+    // no hypotheses: no inliers, so the refit takes every point
+    int rc = ransac_run(ctx, 1, off, x, y, K, nullptr, 0, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, false, &b);
+    if (rc == SFM_OK) rc = sfm_ransac_batch_refit(b);
+    if (rc == SFM_OK) rc = sfm_ransac_batch_refit_fetch(b, pose16_out, nullptr, points_out);
     sfm_ransac_batch_destroy(b);
     return rc;
 }

@@ -129,6 +129,24 @@ namespace sfm_amd
             return static_cast<int>(value);
         }
 
+        EightPointResult eightPointAlgorithm(const std::vector<Vec2> &points1, const std::vector<Vec2> &points2)
+        {
+            if (points1.size() < 8) // eightPoint.cpp:59-62
+                throw std::invalid_argument("EightPointAlgorithm: There have to be at least 8 pair-to-pair-correspondences (was: " +
+                                            std::to_string(points1.size()) + ") to approximate a pose.");
+            if (points2.size() < points1.size())
+                throw std::invalid_argument("EightPointAlgorithm: points2 is shorter than points1");
+            sfm_ctx *ctx = default_context();
+            EightPointResult r;
+            r.points.resize(points1.size());
+            double pose16[16];
+            int rc = sfm_eight_point_algorithm(ctx, &points1[0][0], &points2[0][0], (int)points1.size(), pose16, &r.points[0][0]);
+            if (rc != SFM_OK) fail(ctx, rc, "sfm_eight_point_algorithm");
+            for (int c = 0; c < 4; c++)
+                for (int q = 0; q < 4; q++) r.pose(q, c) = pose16[q + 4 * c];
+            return r;
+        }
+
         EightPointResult eightPointAlgorithmFromSubset(const std::vector<Vec2> &calcPoints1, const std::vector<Vec2> &calcPoints2,
                                                        const std::vector<Vec2> &allPoints1, const std::vector<Vec2> &allPoints2)
         {

@@ -93,6 +93,10 @@ namespace sfm_amd
 
     namespace solve
     {
+        // solve.hpp:69 / eightPoint.cpp:57-223: pose and triangulated points from all correspondences
+        // (the refit on RANSAC's inliers, scene.cpp:288).  Throws std::invalid_argument below 8 points.
+        EightPointResult eightPointAlgorithm(const std::vector<Vec2> &points1, const std::vector<Vec2> &points2);
+
         // solve.hpp:78.  Runs on the device inside RANSAC(); its address marks the default
         // model.  Calling it on the host fits the pose on the device and triangulates there too.
         EightPointResult eightPointAlgorithmFromSubset(const std::vector<Vec2> &calcPoints1,

@@ -85,6 +85,22 @@ int main(int argc, char **argv)
     auto inl = solve::RANSAC(x, y, K, ro, true);
     if (!solve::RANSAC(x, std::vector<Vec2>(y.begin(), y.begin() + 3), K, ro, false).empty()) return 5;
 
+    // scene.cpp:264-298: refit on the inliers
+    std::vector<Vec2> in1, in2;
+    for (int v : inl) {
+        in1.push_back(x[v]);
+        in2.push_back(y[v]);
+    }
+    EightPointResult refit;
+    if (in1.size() >= 8) refit = solve::eightPointAlgorithm(in1, in2);
+    threw = false;
+    try {
+        solve::eightPointAlgorithm(std::vector<Vec2>(x.begin(), x.begin() + 7), std::vector<Vec2>(y.begin(), y.begin() + 7));
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    if (!threw) return 6;
+
     FILE *o = fopen(argv[2], "wb");
     if (!o) return 2;
     int32_t nm = (int32_t)m.size(), ni = (int32_t)inl.size();
@@ -99,6 +115,10 @@ int main(int argc, char **argv)
         int32_t q = v;
         fwrite(&q, 4, 1, o);
     }
+    int32_t np3 = (int32_t)refit.points.size();
+    fwrite(&np3, 4, 1, o);
+    fwrite(refit.pose.data(), 8, 16, o);
+    if (np3) fwrite(&refit.points[0][0], 8, (size_t)np3 * 3, o);
     fclose(o);
     return 0;
 }

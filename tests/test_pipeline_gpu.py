@@ -32,6 +32,7 @@ def test_default_run_stand_in(ctx, oracle, sequence):
     batch = corr.ransac(K, N_HYP, SEED, max_sq_err=1.0, success_prob=0.999, adaptive=True)
     best = batch.best()
     ioff, inl = batch.inliers()
+    rpose, rused, rpts = batch.refit(len(x))
 
     for k, (a, b) in enumerate(pl):
         A, B = slice(a * N_FEAT, (a + 1) * N_FEAT), slice(b * N_FEAT, (b + 1) * N_FEAT)
@@ -57,6 +58,16 @@ def test_default_run_stand_in(ctx, oracle, sequence):
         Rg = best["pose12"][k][:9].reshape(3, 3)
         ang = np.degrees(np.arccos(np.clip((np.trace(Rg @ R_rel.T) - 1) / 2, -1, 1)))
         assert ang < 0.5, f"pair {k}: rotation off by {ang} deg"
+        # refit on the inliers (scene.cpp:288): floating point, a different but equivalent route to the
+        # null vector than the restatement's -> tolerance 1e-8 on the pose, 1e-6 relative on the points
+        # (one float ulp of the depth, eightPoint.cpp:216, is 6e-8)
+        epose, epts, _, _ = oracle.eight_point(ex[r["inliers"]], ey[r["inliers"]])
+        assert rused[k] == len(r["inliers"])
+        assert np.abs(rpose[k] - epose).max() < 1e-8, f"pair {k}: refit pose"
+        got = rpts[off[k]:off[k] + rused[k]]
+        assert np.abs(got - epts).max() <= 1e-6 * np.abs(epts).max(), f"pair {k}: refit points"
+        ang = np.degrees(np.arccos(np.clip((np.trace(rpose[k][:3, :3] @ R_rel.T) - 1) / 2, -1, 1)))
+        assert ang < 0.2, f"pair {k}: refit rotation off by {ang} deg"
     s.close()
 
 
@@ -82,3 +93,46 @@ def test_sample_table_small_counts(ctx, oracle):
     b = corr.ransac(synth.default_K(), 64, 7)
     assert b.best()["count"][1] == 0  # RANSAC.cpp:148-149: fewer than minN correspondences, no result
     s.close()
+
+
+def test_refit_falls_back_to_all_points(ctx, oracle):
+    """Fewer than 8 inliers: the refit uses every correspondence (scene.cpp:294-298); fewer than 8
+    correspondences: identity pose, no points."""
+    tv = synth.two_view(40, inlier_ratio=1.0, seed=3, noise_px=0.0)
+    junk = np.random.default_rng(1).uniform(-0.5, 0.5, (12, 2))
+    x = np.concatenate([tv["x"], junk, tv["x"][:5]])
+    y = np.concatenate([tv["y"], junk[::-1], tv["y"][:5]])
+    off = np.array([0, 40, 52, 57], np.int64)
+    samples = np.zeros((3, 4, 8), np.int32)
+    samples[0] = synth.sample_table(40, 4, seed=1)
+    samples[1] = synth.sample_table(12, 4, seed=2)
+    b = ctx.ransac_batch(off, x, y, tv["K"], samples, 4, max_sq_err=1e-9)
+    cnt = b.best()["count"]
+    assert cnt[0] >= 8 and cnt[1] < 8 and cnt[2] == 0
+    pose, used, pts = b.refit(len(x))
+    assert list(used) == [cnt[0], 12, 0]
+    _, inl = b.inliers()
+    e0, p0, _, _ = oracle.eight_point(x[:40][inl[:cnt[0]]], y[:40][inl[:cnt[0]]])
+    e1, p1, _, _ = oracle.eight_point(x[40:52], y[40:52])
+    assert np.abs(pose[0] - e0).max() < 1e-8 and np.abs(pose[1] - e1).max() < 1e-6
+    assert np.array_equal(pose[2], np.eye(4))
+    assert np.abs(pts[:cnt[0]] - p0).max() <= 1e-6 * np.abs(p0).max()
+
+
+@pytest.mark.parametrize("n", [8, 9, 100, 3000])
+def test_eight_point_algorithm(ctx, oracle, n):
+    tv = synth.two_view(n, inlier_ratio=1.0, seed=n, noise_px=0.2)
+    pose, pts = ctx.eight_point_algorithm(tv["x"], tv["y"])
+    epose, epts, _, _ = oracle.eight_point(tv["x"], tv["y"])
+    tol = 1e-8 if n > 9 else 1e-5  # 8 or 9 points: the fit is exact or nearly so, hence ill-conditioned in the noise
+    assert np.abs(pose - epose).max() < tol
+    assert np.abs(pts - epts).max() <= max(1e-6, 10 * tol) * np.abs(epts).max()
+    if n >= 100:
+        ang = np.degrees(np.arccos(np.clip((np.trace(pose[:3, :3] @ tv["R"].T) - 1) / 2, -1, 1)))
+        assert ang < 1.0
+
+
+def test_eight_point_algorithm_needs_eight_points(ctx):
+    with pytest.raises(capi.SfmError) as e:
+        ctx.eight_point_algorithm(np.zeros((7, 2)), np.zeros((7, 2)))
+    assert e.value.code == capi.ERR_INVALID_ARG and "at least 8" in str(e.value)
