@@ -237,8 +237,11 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
         "inlier_ratio": 0.15, "dtype": "f64",
         "hbm_GBps_algorithmic": round(pairs_s * RANSAC_BYTES_PER_PAIR / 1e9, 3),
         "score_kernel_ms_per_step": round(kms / steps, 3),
-        "score_kernel_fp64_TFLOPs": round(evals_s * RANSAC_FLOPS_PER_EVAL / 1e12, 3),
+        "score_kernel_algorithmic_fp64_TFLOPs": round(evals_s * RANSAC_FLOPS_PER_EVAL / 1e12, 3),
         "fp64_vector_peak_TFLOPs": PEAK_F64_VEC_TFLOPS,
+        "flops_note": "algorithmic = every (hypothesis, correspondence) evaluation at 92 fp64 flops; the kernel proves "
+                      "most of them outliers with a packed-fp32 epipolar-distance test and evaluates only the rest, "
+                      "so this figure can exceed the fp64 vector peak; results are bit-identical to evaluating all",
         "mean_best_inliers": float(np.mean(best["count"])),
     }
 

@@ -498,7 +498,33 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     using AccT = typename std::conditional<MF16 != 0, Acc16<RT>, Acc32<RT>>::type;
     auto mfma_step = [&](AccT &acc, int buf, int sub) {
         acc.zero();
-        if constexpr (MF16 != 0) {
+        if constexpr (MF16 == 2) {
+            // B fragments one ahead of their use: the LDS read of fragment k + 1 is issued before the
+            // MFMAs of fragment k, so its latency hides behind them
+            auto ldb = [&](int idx) {
+                const int row = sub * 32 + (idx >> 2) * 16 + (lane & 15);
+                return *reinterpret_cast<const half8 *>(&lds[buf][row * 256 + (((4 * (idx & 3) + (lane >> 4)) ^ (row & 15)) << 4)]);
+            };
+            half8 bc = ldb(0);
+#pragma unroll
+            for (int idx = 0; idx < 8; idx++) {
+                half8 bn = bc;
+                if (idx < 7) bn = ldb(idx + 1);
+#pragma unroll
+                for (int t = 0; t < 2 * RT; t++)
+                    acc.a[idx >> 2][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][idx & 3], bc, acc.a[idx >> 2][t], 0, 0, 0);
+                bc = bn;
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+            for (int idx = 0; idx < 7; idx++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT, 0);
+#endif
+        } else if constexpr (MF16 != 0) {
 #pragma unroll
             for (int ct = 0; ct < 2; ct++)
 #pragma unroll
@@ -638,6 +664,8 @@ static const SimVariant kSimVariants[] = {
     SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 0),  // 10: ablation of 4, neither staging nor test
     SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 1),  // 11: ablation of 5, no candidate test
     SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 1),  // 12: ablation of 5, neither
+    SIM_VARIANT(2, 4, 64, 4, 0, 0, 2, 2),  // 13: 8 with B fragments read one ahead
+    SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 2),  // 14: 5 with B fragments read one ahead
 };
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 

@@ -26,6 +26,7 @@
 #pragma clang fp contract(off)
 
 #define SCORE_CH 256 // correspondences staged in LDS per step
+#define SCORE_QCAP 8 // per-lane queue of correspondences awaiting exact evaluation
 #define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
 
 struct RansacArgs {
@@ -433,10 +434,22 @@ __device__ __forceinline__ void load_pose(const double *src, Pose &P)
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat(float v)
+{
+    f32x2 r;
+    r.x = v;
+    r.y = v;
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <int LOSS>
 __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
 {
     __shared__ __attribute__((aligned(16))) double rec[SCORE_CH * REC_D];
+    __shared__ unsigned short pend[SCORE_QCAP][256]; // per-lane queues of chunk-local correspondence indices
+    __shared__ __attribute__((aligned(16))) float rec32[(SCORE_CH / 2) * 12];
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
     const int h = blockIdx.x * 256 + tid;
@@ -451,57 +464,100 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
 #pragma unroll
     for (int i = 0; i < 9; i++) K[i] = g.K[i];
     const double thr = g.maxSqErr;
-    const double thr4 = 4.0 * thr;
     const bool filterOn = g.filter != 0;
-    const double Ki00 = g.Ki[0], Ki01 = g.Ki[1], Ki10 = g.Ki[2], Ki11 = g.Ki[3];
+    // fp32 splats for the pre-test
+    f32x2 Ef[9], Kif[4];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Ef[i] = splat((float)E[i / 3][i % 3]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) Kif[i] = splat((float)g.Ki[i]);
+    const f32x2 thr16 = splat((float)(16.0 * thr));
 
     int count = 0;
     double tot = 0.0;
+    // Correspondences that survive the pre-test are not evaluated on the spot (one lane in a few
+    // hundred needs it at any time, and the whole wave would walk through the long exact path for
+    // it) but queued per lane and evaluated together: every lane then works on an entry of its own.
+    // A lane drains its queue in order, so its count and error sum still accumulate in
+    // correspondence order (RANSAC.cpp:207-221).
+    int npend = 0;
+    auto evaluate = [&](int kk) {
+        const double *r = rec + kk * REC_D;
+        const double e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+        if (e < thr) { // RANSAC.cpp:216-220
+            count++;
+            tot += e;
+        }
+    };
+    auto drain = [&]() {
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < npend) != 0; i++)
+            if (i < npend) evaluate(pend[i][tid]);
+        npend = 0;
+    };
     for (int k0 = 0; k0 < n; k0 += SCORE_CH) {
         const int m = min(SCORE_CH, n - k0);
         const double2 *src = reinterpret_cast<const double2 *>(g.rec + (base + k0) * REC_D);
         for (int q = tid; q < m * (REC_D / 2); q += 256) reinterpret_cast<double2 *>(rec)[q] = src[q];
         __syncthreads();
-        for (int kk = 0; kk < m; kk++) {
-            const double *r = rec + kk * REC_D;
-            if (LOSS == SFM_LOSS_SAMPSON) {
+        if (LOSS != SFM_LOSS_SAMPSON && filterOn) { // fp32 copies for the pre-test, two correspondences interleaved
+            for (int q = tid; q < ((m + 1) & ~1); q += 256) {
+                float *d = rec32 + (q >> 1) * 12 + (q & 1);
+                const double *r = rec + q * REC_D;
+                const bool real = q < m;
+                d[0] = real ? (float)r[0] : 0.0f;
+                d[2] = real ? (float)r[1] : 0.0f;
+                d[4] = real ? (float)r[2] : 0.0f;
+                d[6] = real ? (float)r[3] : 0.0f;
+                d[8] = real ? (float)r[9] : 0.0f;
+                d[10] = real ? (float)r[4] : 0.0f;
+            }
+            __syncthreads();
+        }
+        if (LOSS == SFM_LOSS_SAMPSON) {
+            for (int kk = 0; kk < m; kk++) {
+                const double *r = rec + kk * REC_D;
                 const double e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
                 if (e < thr) {
                     count++;
                     tot += e;
                 }
-                continue;
             }
-            // Pre-test.  Whatever depth the triangulation picks, the point lies on the ray of
-            // x1, so its image in camera 2 lies on the epipolar line of x1; the camera-2
-            // reprojection error is therefore at least the distance from the observation to that
-            // line.  If that distance is at least twice sqrt(maxSquaredError) the correspondence
-            // cannot be an inlier of this hypothesis and the exact evaluation is skipped.  Guards:
-            // the line must be well defined (x1 not within 1e-3 of the epipole: there the
-            // projection of the triangulated point is unstable), the residual must stand clear of
-            // its own rounding noise, and the observation must be an ordinary pixel (r[9]).
-            bool need = true;
-            if (filterOn) {
-                const double x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-                const double m0 = fma(E[0][0], x1, fma(E[0][1], y1, E[0][2]));
-                const double m1 = fma(E[1][0], x1, fma(E[1][1], y1, E[1][2]));
-                const double m2 = fma(E[2][0], x1, fma(E[2][1], y1, E[2][2]));
-                const double num = fma(x2, m0, fma(y2, m1, m2));
-                const double l0 = fma(Ki00, m0, Ki10 * m1); // (K^-T m) rows 0, 1: the line in pixels
-                const double l1 = fma(Ki01, m0, Ki11 * m1);
-                const double den2 = fma(l0, l0, l1 * l1);
-                const double msq = fma(m0, m0, fma(m1, m1, m2 * m2));
-                const double mag = fma(fabs(x2), fabs(m0), fma(fabs(y2), fabs(m1), fabs(m2)));
-                const bool skip = (num * num >= thr4 * den2) && (msq >= 1e-6 * r[9]) && (fabs(num) >= 1e-9 * mag);
-                need = !skip;
+        } else if (!filterOn) {
+            for (int kk = 0; kk < m; kk++) evaluate(kk);
+        } else {
+            // Pre-test, in packed fp32 (two correspondences per instruction).  Whatever depth the
+            // triangulation picks, the point lies on the ray of x1, so its image in camera 2 lies
+            // on the epipolar line of x1; the camera-2 reprojection error is therefore at least
+            // the distance from the observation to that line.  If the fp32 estimate of that
+            // distance is at least four times sqrt(maxSquaredError), the correspondence cannot be
+            // an inlier of this hypothesis and the exact evaluation is skipped.  Guards keep the
+            // estimate within a few per cent of the truth, far inside the factor of four: the
+            // line direction must be well defined (|m01| >= 1e-3 |x1h|: fp32 noise in m is
+            // ~1e-7 |x1h|, and near the epipole the reference's own projection is unstable), the
+            // residual must stand clear of its rounding noise (|num| >= 1e-4 |x2h| |m|), and the
+            // observation must be an ordinary pixel (r9 = inf otherwise).  NaNs fail every test.
+            for (int kk = 0; kk < m; kk += 2) {
+                const f32x2 *rp = reinterpret_cast<const f32x2 *>(rec32 + (kk >> 1) * 12);
+                const f32x2 x1 = rp[0], y1 = rp[1], x2 = rp[2], y2 = rp[3], r9 = rp[4], r4 = rp[5];
+                const f32x2 m0 = pk_fma(Ef[0], x1, pk_fma(Ef[1], y1, Ef[2]));
+                const f32x2 m1 = pk_fma(Ef[3], x1, pk_fma(Ef[4], y1, Ef[5]));
+                const f32x2 m2 = pk_fma(Ef[6], x1, pk_fma(Ef[7], y1, Ef[8]));
+                const f32x2 num = pk_fma(x2, m0, pk_fma(y2, m1, m2));
+                const f32x2 l0 = pk_fma(Kif[0], m0, Kif[2] * m1); // (K^-T m) rows 0, 1: the line in pixels
+                const f32x2 l1 = pk_fma(Kif[1], m0, Kif[3] * m1);
+                const f32x2 den2 = pk_fma(l0, l0, l1 * l1) * thr16;
+                const f32x2 m01 = pk_fma(m0, m0, m1 * m1);
+                const f32x2 msq = pk_fma(m2, m2, m01);
+                const f32x2 n2 = num * num;
+                const f32x2 g1 = r9 * 1e-6f, g2 = (r4 * 1e-8f) * msq;
+                const bool skip0 = n2.x >= den2.x && m01.x >= g1.x && n2.x >= g2.x;
+                const bool skip1 = n2.y >= den2.y && m01.y >= g1.y && n2.y >= g2.y;
+                if (!skip0) pend[npend++][tid] = (unsigned short)kk;
+                if (!skip1 && kk + 1 < m) pend[npend++][tid] = (unsigned short)(kk + 1);
+                // room for the next four: drain as soon as any lane of the wave holds more than four
+                if ((kk & 2) && __builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 4) != 0) drain();
             }
-            if (need) {
-                const double e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
-                if (e < thr) { // RANSAC.cpp:216-220
-                    count++;
-                    tot += e;
-                }
-            }
+            drain(); // the queue indexes this chunk's records
         }
         __syncthreads();
     }
