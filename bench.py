@@ -25,6 +25,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of MI355X
+PEAK_I8_TOPS = 5000.0      # dense int8 MFMA peak: the 16x16x64 int8 form takes the cycles of the bf16 16x16x32 form at twice the K
+BOUNDS = {"int8": (16, "i8", PEAK_I8_TOPS), "fp16": (8, "f16", PEAK_F16_TFLOPS)}  # sim_variant, dtype, peak
 PEAK_F64_VEC_TFLOPS = 78.6  # fp64 vector peak
 RANSAC_BYTES_PER_PAIR = 1_082_368  # 20 000 corr * 32 B + 4096 hyp * (96 + 12) B
 RANSAC_FLOPS_PER_EVAL = 92
@@ -41,6 +43,8 @@ def main():
     ap.add_argument("--ransac-pairs", type=int, default=64)
     ap.add_argument("--ransac-corr", type=int, default=20000)
     ap.add_argument("--ransac-hyps", type=int, default=4096)
+    ap.add_argument("--bound", choices=sorted(BOUNDS), default="int8",
+                    help="arithmetic of the matcher's similarity bound (the exact re-scoring is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=3, help="8192x8192 pairs the CPU baseline matches")
@@ -61,6 +65,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     ctx = capi.Context(local_rank)
+    sim_variant, bound_dtype, bound_peak = BOUNDS[args.bound]
+    ctx.set_option("sim_variant", sim_variant)
 
     # ---- workload: weak scaling, pairs_per_gpu fixed ---------------------------------------
     pairs_per_gpu = args.images * (args.images - 1) // 2
@@ -134,8 +140,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16",
-        "dtype_note": "fp16-in/fp32-acc MFMA bounds every cell; cells that can pass are re-scored in the "
+        "dtype": bound_dtype,
+        "dtype_note": ("int8-in/int32-acc" if args.bound == "int8" else "fp16-in/fp32-acc") +
+                      " MFMA bounds every cell; cells that can pass are re-scored in the "
                       "reference's fp32 operation order, so match lists are bit-exact",
         "data": "synthetic",
         "config": {
@@ -148,10 +155,11 @@ def main():
         },
         "roofline": {
             "bound": "mfma", "kernel": "match_sim_kernel",
-            "achieved": round(achieved_tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved_tflops / PEAK_F16_TFLOPS, 4),
-            "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1)),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass, profiles/r1_pmc_traffic.json)",
+            "achieved": round(achieved_tflops, 2), "peak": bound_peak, "unit": "TFLOP/s",
+            "unit_note": "algorithmic 2*N*M*D operations per pair; with the int8 bound they are integer multiply-adds",
+            "frac": round(achieved_tflops / bound_peak, 4),
+            "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1), args.bound),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r1_pmc_traffic*.json)",
             "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4), "launches": kernel_launches,
             "flops_per_pair": flops_per_pair,
         },
@@ -172,11 +180,11 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(pairs_per_launch):
+def measured_traffic(pairs_per_launch, bound="int8"):
     """HBM bytes per launch of the similarity kernel from the committed PMC pass (FETCH_SIZE and
     WRITE_SIZE are collected by rocprofv3 in separate runs of this script, not inline), scaled to
     this run's pairs per launch; None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_i8.json" if bound == "int8" else "r1_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:

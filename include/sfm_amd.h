@@ -62,8 +62,9 @@ const char *sfm_version(void);
 /* Tunables (all optional).  key: "cand_capacity" (candidate slots per image
  * pair, default 524288; pairs that need more are scored cell by cell),
  * "pairs_per_launch" (default 2048), "hyps_per_launch", "sim_variant"
- * (instance of the similarity kernel, 0 .. 12; 9 and above are timing-only
- * ablations with wrong results), "ransac_filter" (1 = skip evaluations the
+ * (instance of the similarity kernel: 16 = int8 bound, the default; 8 = fp16
+ * bound; the instances documented as ablations in match.hip give wrong
+ * results and exist for timing only), "ransac_filter" (1 = skip evaluations the
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
  * everything; results are identical).  Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */
@@ -134,6 +135,10 @@ int sfm_match_result_device(sfm_match_result *res, const int64_t **offsets_devic
 /* Number of candidate cells the exact pass evaluated / that did not fit the
  * candidate list and were evaluated inside the similarity kernel. */
 int sfm_match_result_stats(sfm_match_result *res, int64_t *candidates_out, int64_t *overflow_out);
+/* stats4_out[0] candidates re-scored exactly, [1] pairs scored cell by cell,
+ * [2] pairs that needed the filtered (row-best / column-best) passes, [3] pairs
+ * whose int8 bound admitted too many cells and that the fp16 bound settled. */
+int sfm_match_result_stats_ex(sfm_match_result *res, int64_t *stats4_out);
 void sfm_match_result_destroy(sfm_match_result *res);
 
 /* ---- RANSAC: one image pair -------------------------------------------------

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "sfm_ctx_set_option", "sfm_ctx_last_kernel_ms",
     "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_device", "sfm_imageset_destroy",
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
-    "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats",
+    "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
     "sfm_match_result_destroy",
     "sfm_ransac_pair", "sfm_eight_point_fit", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.sfm_match_result_pairs.argtypes = [vp, vp]
     L.sfm_match_result_device.argtypes = [vp, P(vp), P(vp)]
     L.sfm_match_result_stats.argtypes = [vp, P(i64), P(i64)]
+    L.sfm_match_result_stats_ex.argtypes = [vp, vp]
     L.sfm_match_result_destroy.argtypes = [vp]
     L.sfm_match_result_destroy.restype = None
     L.sfm_ransac_pair.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, f64, f64, i32, i32, vp, i32, P(i32),
@@ -318,6 +319,13 @@ class MatchResult:
         a, b = C.c_int64(0), C.c_int64(0)
         self.ctx.check(lib().sfm_match_result_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def stats_ex(self):
+        """(candidates re-scored, pairs scored cell by cell, pairs that needed the filtered passes,
+        pairs settled by the fp16 bound after the int8 bound flooded)."""
+        out = np.zeros(4, np.int64)
+        self.ctx.check(lib().sfm_match_result_stats_ex(self._h, _ptr(out)))
+        return tuple(int(v) for v in out)
 
     def close(self):
         if self._h:

@@ -34,6 +34,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
+typedef int int4v __attribute__((ext_vector_type(4)));
 
 #define KDIM 128         // padded descriptor length of the fp16 table
 #define ROW_PAD 1024     // every image's fp16 rows are padded to a multiple of this
@@ -45,6 +46,7 @@ typedef unsigned long long u64;
 
 struct MatchArgs {
     const _Float16 *desc16;
+    const signed char *desc8; // unit-normalised descriptors quantised to int8, 128 bytes per row
     const float *desc32;
     const float *norms;
     const double2 *pts;
@@ -52,13 +54,13 @@ struct MatchArgs {
     const int2 *work;     // (pair in chunk, row block), -1 = no work
     uint2 *cand;          // [pairs in chunk][candCap]
     int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
-    int *pairOvf;         // [pairs in chunk]: 1 = a slice overflowed in the strict pass, 2 = in the general pass
-    int onlyFlagged;      // general pass over the pairs flagged 1 only
+    int *pairOvf;         // [pairs in chunk]: a slice overflowed in 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
+    int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
     int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
     int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
     u64 *best;            // row keys and column keys of the chunk
     int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
-    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell
+    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell, [2] pairs that needed the filtered passes, [3] pairs settled by the fp16 strict pass after the int8 one flooded
     int candCap;
     int blockRows;        // rows of image A per block of the similarity kernel instance in use
     int wavesPerBlock;
@@ -114,6 +116,56 @@ __global__ void ingest_f16_kernel(const float *__restrict__ desc32, const ImageR
         out[e] = (_Float16)v;
     }
     *reinterpret_cast<half8 *>(desc16 + (size_t)(im.row16 + r) * KDIM + k0) = out;
+}
+
+// Per image, over its unit-normalised descriptors a / |a|: the largest |element| and the largest L1
+// norm (as int bit patterns of non-negative floats, so atomicMax orders them).  One thread per descriptor.
+__global__ void ingest_stats_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+                                    const float *__restrict__ norms, int dim, int *__restrict__ stats)
+{
+    const ImageRec im = images[blockIdx.y];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= im.n) return;
+    const float s = norms[im.row32 + r];
+    if (!((s >= 1e-12f) && (s <= 1e12f))) return;
+    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
+    float mx = 0.0f, l1 = 0.0f;
+    for (int k = 0; k < dim; k++) {
+        const float v = fabsf(__fdiv_rn(a[k], s));
+        mx = fmaxf(mx, v);
+        l1 += v;
+    }
+    atomicMax(&stats[2 * blockIdx.y], __float_as_int(mx));
+    atomicMax(&stats[2 * blockIdx.y + 1], __float_as_int(l1 * 1.0001f)); // the sum's own rounding
+}
+
+// One thread per 16 elements of the int8 table: round(a / norm * scale), scale = ImageRec::scale8.
+__global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+                                 const float *__restrict__ norms, int dim, signed char *__restrict__ desc8)
+{
+    const ImageRec im = images[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t >> 3, k0 = (t & 7) * 16;
+    if (r >= im.n) return;
+    const float s = norms[im.row32 + r];
+    const bool ok = (s >= 1e-12f) && (s <= 1e12f);
+    const float scale = __int_as_float(im.pad);
+    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
+    int4v out;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int k = k0 + 4 * w + e;
+            float v = 0.0f;
+            if (ok && k < dim) v = rintf(__fdiv_rn(a[k], s) * scale);
+            const int q = (int)fminf(fmaxf(v, -127.0f), 127.0f);
+            packed |= (unsigned)(q & 0xFF) << (8 * e);
+        }
+        out[w] = (int)packed;
+    }
+    *reinterpret_cast<int4v *>(desc8 + (size_t)(im.row16 + r) * 128 + k0) = out;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -218,6 +270,7 @@ __device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int 
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 template <int RT> struct Acc32 {
+    typedef float VT;
     static constexpr int NV = RT * 16, NGROUP = 1, GROUP = NV;
     float16v a[RT];
     __device__ __forceinline__ void zero()
@@ -237,6 +290,7 @@ template <int RT> struct Acc32 {
 };
 
 template <int RT> struct Acc16 {
+    typedef float VT;
     static constexpr int RT16 = RT * 2, NV = 2 * RT16 * 4, NGROUP = 2, GROUP = RT16 * 4;
     float4v a[2][RT16];
     __device__ __forceinline__ void zero()
@@ -254,6 +308,25 @@ template <int RT> struct Acc16 {
         return ((idx % GROUP) >> 2) * 16 + 4 * (lane >> 4) + (idx & 3);
     }
     __device__ static __forceinline__ int col(int idx, int lane) { return (idx / GROUP) * 16 + (lane & 15); }
+};
+
+// 16x16x64 int8 MFMA: the same value-to-cell map as Acc16, int32 values.
+template <int RT> struct Acc16i {
+    typedef int VT;
+    static constexpr int RT16 = RT * 2, NV = 2 * RT16 * 4, NGROUP = 2, GROUP = RT16 * 4;
+    int4v a[2][RT16];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int t = 0; t < RT16; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[c][t][q] = 0;
+    }
+    __device__ __forceinline__ int get(int idx) const { return a[idx / GROUP][(idx % GROUP) >> 2][idx & 3]; }
+    __device__ static __forceinline__ int row(int idx, int lane) { return Acc16<RT>::row(idx, lane); }
+    __device__ static __forceinline__ int col(int idx, int lane) { return Acc16<RT>::col(idx, lane); }
 };
 
 // What the general instance keeps in LDS besides the staged descriptors: the pixel positions of
@@ -285,13 +358,20 @@ struct GeneralLds {
 // trails the shared bound, which keeps the test permissive.
 template <typename AccT, bool DOT, bool GENERAL>
 __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
-                                             int colBase, int lane, float thr_m, WaveQueue &wq,
+                                             int colBase, int lane, typename AccT::VT thr_m, WaveQueue &wq,
                                              float (&localLo)[GENERAL ? AccT::NV : 1], const GeneralLds &gl)
 {
     constexpr int NV = AccT::NV;
     static_assert(NV <= 32, "one bit per accumulator value");
     unsigned bits = 0;
-    if constexpr (!GENERAL) {
+    constexpr bool INTEGER = std::is_same<typename AccT::VT, int>::value;
+    static_assert(!INTEGER || !GENERAL, "the int8 bound has a strict instance only");
+    if constexpr (INTEGER) {
+        int m[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+        for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = max(max(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
+        bits = max(max(m[0], m[1]), max(m[2], m[3])) > thr_m;
+    } else if constexpr (!GENERAL) {
         // fmaxf ignores NaNs, and a NaN cell can never be accepted.  Four independent chains keep
         // the dependent-issue latency short; no branch, so the chain can be scheduled among MFMAs.
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -312,9 +392,11 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
     // rare path
     const int z = opaque_zero();
     const int ln = lane + z;
-    if (!(thr_m > -INFINITY)) { // norms out of range: no bound holds, score the pair cell by cell
-        wq.n = wq.cap + 1;
-        return;
+    if constexpr (!INTEGER) {
+        if (!(thr_m > -INFINITY)) { // norms out of range: no bound holds, score the pair cell by cell
+            wq.n = wq.cap + 1;
+            return;
+        }
     }
 
     bool swapped = false;
@@ -405,6 +487,16 @@ template <int RT> __device__ __forceinline__ void keep_alive(const Acc16<RT> &ac
 #endif
 }
 
+template <int RT> __device__ __forceinline__ void keep_alive(const Acc16i<RT> &acc)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int t = 0; t < 2 * RT; t++) asm volatile("" ::"v"(acc.a[c][t]));
+#endif
+}
+
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -417,10 +509,13 @@ template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL, int 
 __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
 {
     constexpr int NSUB = BN_ / 32;
-    constexpr int DMA = BN_ * 256 / 1024 / WAVES; // LDS-DMA instructions per wave per step
-    static_assert(BN_ * 256 % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
+    constexpr bool I8 = MF16 == 3;        // int8 table, 16x16x64 MFMA, integer bound
+    constexpr int ROWB = I8 ? 128 : 256;  // bytes per descriptor row in the table and in LDS
+    constexpr int DMA = BN_ * ROWB / 1024 / WAVES; // LDS-DMA instructions per wave per step
+    static_assert(BN_ * ROWB % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
     static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * 256];
+    static_assert(!I8 || (!GENERAL && !DOT && !PIPE), "the int8 bound has a strict cosine instance only");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * ROWB];
     // general instance: positions of the block's rows, of the staged columns, and the row bounds
     constexpr int BLOCK_ROWS = WAVES * RT * 32;
     __shared__ double2 ptsRow[GENERAL ? BLOCK_ROWS : 1];
@@ -431,7 +526,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     static_assert(GENERAL || !DOT, "the dot metric needs the general instance");
     const int2 w = g.work[blockIdx.x];
     if (w.x < 0) return;
-    if (g.onlyFlagged && g.pairOvf[w.x] != 1) return; // second pass: pairs the strict pass gave up on
+    if (g.onlyFlagged && g.pairOvf[w.x] != g.onlyFlagged) return; // later passes: pairs an earlier pass gave up on
     PairRec pr = g.pairs[w.x];
     // slices of the pair's candidate list: one per wave of the strict pass, or one per wave of
     // both orientations of the general pass
@@ -449,33 +544,49 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     const int rowBase = w.y * (WAVES * RT * 32) + wave * (RT * 32);
 
     const _Float16 *A16 = g.desc16 + (size_t)(pr.rowA16 + rowBase) * KDIM;
-    const unsigned char *B16 = reinterpret_cast<const unsigned char *>(g.desc16 + (size_t)pr.rowB16 * KDIM);
+    const unsigned char *B16 = I8 ? reinterpret_cast<const unsigned char *>(g.desc8) + (size_t)pr.rowB16 * 128
+                                  : reinterpret_cast<const unsigned char *>(g.desc16 + (size_t)pr.rowB16 * KDIM);
 
     // A fragments.  32x32x16: a[t][s] = rows 32t + (l & 31), k = 16s + 8(l >> 5) .. +7.
     //               16x16x32: a[t][s] = rows 16t + (l & 15), k = 32s + 8(l >> 4) .. +7.
-    constexpr int NA_T = MF16 ? 2 * RT : RT, NA_S = MF16 ? 4 : 8;
+    //               16x16x64 (int8): a8[t][s] = rows 16t + (l & 15), k = 64s + 16(l >> 4) .. +15.
+    constexpr int NA_T = MF16 ? 2 * RT : RT, NA_S = I8 ? 1 : (MF16 ? 4 : 8);
     half8 a[NA_T][NA_S];
+    int4v a8[I8 ? 2 * RT : 1][2];
+    if constexpr (I8) {
+        const unsigned char *A8 = reinterpret_cast<const unsigned char *>(g.desc8) + (size_t)(pr.rowA16 + rowBase) * 128;
 #pragma unroll
-    for (int t = 0; t < NA_T; t++)
+        for (int t = 0; t < 2 * RT; t++)
 #pragma unroll
-        for (int s = 0; s < NA_S; s++)
-            a[t][s] = MF16 ? *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 16 + (lane & 15)) * KDIM + s * 32 + (lane >> 4) * 8)
-                           : *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
+            for (int s = 0; s < 2; s++)
+                a8[t][s] = *reinterpret_cast<const int4v *>(A8 + (size_t)(t * 16 + (lane & 15)) * 128 + s * 64 + (lane >> 4) * 16);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NA_T; t++)
+#pragma unroll
+            for (int s = 0; s < NA_S; s++)
+                a[t][s] = MF16 ? *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 16 + (lane & 15)) * KDIM + s * 32 + (lane >> 4) * 8)
+                               : *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
+    }
 
     const int nChunks = (pr.nB + BN_ - 1) / BN_;
     // the bound is the same for the whole block: keep it (and the branch on it) scalar
     const float thr_m = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m)));
+    const int thr_i = __builtin_amdgcn_readfirstlane(pr.thr_i);
 
     // LDS-DMA: instruction u of this wave fills 1 KiB = rows 4*blk .. 4*blk+3 of the step; lane l
     // lands at row 4*blk + (l >> 4), physical chunk l & 15, which holds logical chunk (l & 15) ^ (row & 15).
+    // int8 rows are 128 B, so a 256-B LDS line holds rows 2L and 2L + 1: 16-B chunk c of row 2L + b
+    // sits at position (8b + c) ^ (L & 15) of line L.
     unsigned srcOff[DMA];
 #pragma unroll
     for (int u = 0; u < DMA; u++) {
-        const int row = 4 * (wave * DMA + u) + (lane >> 4);
-        srcOff[u] = row * 256 + (((lane & 15) ^ (row & 15)) << 4);
+        const int row = 4 * (wave * DMA + u) + (lane >> 4); // 256-B line of the step
+        const int logical = (lane & 15) ^ (row & 15);
+        srcOff[u] = I8 ? (2 * row + (logical >> 3)) * 128 + ((logical & 7) << 4) : row * 256 + (logical << 4);
     }
     auto dma_issue = [&](int c, int buf) {
-        const unsigned char *src = B16 + (size_t)c * BN_ * 256;
+        const unsigned char *src = B16 + (size_t)c * BN_ * ROWB;
 #pragma unroll
         for (int u = 0; u < DMA; u++)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + srcOff[u]), (lptr_t)&lds[buf][(wave * DMA + u) * 1024], 16, 0, 0);
@@ -495,10 +606,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
             rowBound[rr] = 0;
         }
     }
-    using AccT = typename std::conditional<MF16 != 0, Acc16<RT>, Acc32<RT>>::type;
+    using AccT = typename std::conditional<I8, Acc16i<RT>, typename std::conditional<MF16 != 0, Acc16<RT>, Acc32<RT>>::type>::type;
     auto mfma_step = [&](AccT &acc, int buf, int sub) {
         acc.zero();
-        if constexpr (MF16 == 2) {
+        if constexpr (I8) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const int row = sub * 32 + ct * 16 + (lane & 15);
+                    const int line = row >> 1;
+                    const int pos = ((row & 1) * 8 + 4 * s + (lane >> 4)) ^ (line & 15);
+                    const int4v b = *reinterpret_cast<const int4v *>(&lds[buf][line * 256 + (pos << 4)]);
+#pragma unroll
+                    for (int t = 0; t < 2 * RT; t++)
+                        acc.a[ct][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[t][s], b, acc.a[ct][t], 0, 0, 0);
+                }
+        } else if constexpr (MF16 == 2) {
             // B fragments one ahead of their use: the LDS read of fragment k + 1 is issued before the
             // MFMAs of fragment k, so its latency hides behind them
             auto ldb = [&](int idx) {
@@ -559,7 +683,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
         if constexpr ((ABL & 2) != 0)
             keep_alive<RT>(acc);
         else
-            sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, thr_m, wq, localLo,
+            sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, typename AccT::VT(I8 ? thr_i : thr_m), wq, localLo,
                                              GeneralLds{ptsRow + (GENERAL ? wave * RT * 32 : 0),
                                                         &ptsCol[GENERAL ? buf & 1 : 0][GENERAL ? (colBase % BN_) : 0],
                                                         rowBound + (GENERAL ? wave * RT * 32 : 0)});
@@ -633,7 +757,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     if (PIPE) test(accB, jPrev);
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
-        if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = GENERAL ? 2 : 1;
+        if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = GENERAL ? 2 : (I8 ? 3 : 1);
     }
 }
 
@@ -641,15 +765,25 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
 struct SimVariant {
     int blockRows, threads;
     void (*strict)(const MatchArgs);  // cosine, every cell above the bound is queued
+    void (*strict16)(const MatchArgs); // i8 instances: the fp16 strict instance that redoes pairs the int8 bound flooded
     void (*general)(const MatchArgs); // cosine with the row/column-best filter
     void (*dot)(const MatchArgs);
     const char *name;
+    bool i8 = false; // the strict instance bounds with the int8 table
 };
 #define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES, MF16)                                              \
     {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, MF16, false>, \
+     nullptr,                                                                                                   \
      match_sim_kernel<RT, WAVES, BN_, 2, 0, false, ABL, 2, MF16, true>,                                         \
      match_sim_kernel<RT, WAVES, BN_, 2, 0, true, ABL, 2, MF16, true>,                                          \
      "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL "_st" #STAGES "_mf16" #MF16}
+// int8 bound for the strict pass; the general and dot instances are the fp16 ones of the same geometry
+#define SIM_VARIANT_I8(RT, WAVES, BN_, OCC, ABL, STAGES)                                                      \
+    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, 0, false, ABL, STAGES, 3, false>,      \
+     match_sim_kernel<RT, WAVES, 64, 4, 0, false, 0, 2, 1, false>,                                            \
+     match_sim_kernel<RT, WAVES, 64, 2, 0, false, 0, 2, 1, true>,                                             \
+     match_sim_kernel<RT, WAVES, 64, 2, 0, true, 0, 2, 1, true>,                                              \
+     "i8_rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_abl" #ABL "_st" #STAGES, true}
 static const SimVariant kSimVariants[] = {
     SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 0), // 0: 8 waves x 64 rows, one block per CU
     SIM_VARIANT(2, 8, 128, 2, 1, 0, 2, 0), // 1: pipelined candidate test
@@ -666,6 +800,11 @@ static const SimVariant kSimVariants[] = {
     SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 1),  // 12: ablation of 5, neither
     SIM_VARIANT(2, 4, 64, 4, 0, 0, 2, 2),  // 13: 8 with B fragments read one ahead
     SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 2),  // 14: 5 with B fragments read one ahead
+    SIM_VARIANT_I8(2, 4, 64, 4, 0, 2),     // 15: int8 bound, 16x16x64 MFMA, same block geometry as 8
+    SIM_VARIANT_I8(2, 4, 64, 5, 0, 2),     // 16
+    SIM_VARIANT_I8(2, 4, 128, 4, 0, 2),    // 17: 128 descriptors per step
+    SIM_VARIANT_I8(2, 4, 64, 4, 2, 2),     // 18: ablation of 15, no candidate test
+    SIM_VARIANT_I8(2, 4, 64, 4, 3, 2),     // 19: ablation of 15, neither staging nor test
 };
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
@@ -801,8 +940,15 @@ __global__ __launch_bounds__(256) void match_overflow_list_kernel(const MatchArg
     __shared__ int n;
     if (threadIdx.x == 0) n = 0;
     __syncthreads();
-    for (int p = threadIdx.x; p < nPairs; p += blockDim.x)
-        if (g.pairOvf[p] == 2) g.ovfList[1 + atomicAdd(&n, 1)] = p;
+    int general = 0, redone = 0;
+    for (int p = threadIdx.x; p < nPairs; p += blockDim.x) {
+        const int f = g.pairOvf[p];
+        if (f == 2) g.ovfList[1 + atomicAdd(&n, 1)] = p;
+        general += (f == 1 || f == 2);
+        redone += (f == 3);
+    }
+    if (general) atomicAdd(&g.stats[2], (u64)general);
+    if (redone) atomicAdd(&g.stats[3], (u64)redone);
     __syncthreads();
     if (threadIdx.x == 0) {
         g.ovfList[0] = n;
@@ -917,6 +1063,8 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->owns_desc32) s->desc32.release();
     s->desc16.release();
+    s->desc8.release();
+    s->imageStats.release();
     s->norms.release();
     if (s->owns_pts) s->pts.release();
     s->imageRecs.release();
@@ -927,7 +1075,7 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
 extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
 {
     if (!s) return 0;
-    return (int64_t)(s->desc32.cap + s->desc16.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
+    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
 }
 
 static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, const float *desc,
@@ -993,6 +1141,10 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         if (bpts) SET_HIP(hipMemcpyAsync(s->pts.p, pts, bpts, hipMemcpyHostToDevice, ctx->stream));
     }
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
+    SET_HIP(s->desc8.reserve((size_t)r16 * 128));
+    SET_HIP(s->imageStats.reserve((size_t)(n_images ? n_images : 1) * 2 * sizeof(int)));
+    SET_HIP(hipMemsetAsync(s->desc8.p, 0, (size_t)r16 * 128, ctx->stream));
+    SET_HIP(hipMemsetAsync(s->imageStats.p, 0, (size_t)(n_images ? n_images : 1) * 2 * sizeof(int), ctx->stream));
     SET_HIP(s->norms.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(s->imageRecs.reserve((size_t)(n_images ? n_images : 1) * sizeof(ImageRec)));
     SET_HIP(s->imageFlags.reserve((size_t)(n_images ? n_images : 1) * sizeof(int)));
@@ -1011,6 +1163,33 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         SET_HIP(hipGetLastError());
         SET_HIP(hipMemcpyAsync(s->flags.data(), s->imageFlags.p, (size_t)n_images * sizeof(int),
                                hipMemcpyDeviceToHost, ctx->stream));
+        // int8 table: per-image scale from the largest unit-normalised element
+        hipLaunchKernelGGL(ingest_stats_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
+                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>());
+        std::vector<int> stats((size_t)n_images * 2);
+        SET_HIP(hipMemcpyAsync(stats.data(), s->imageStats.p, stats.size() * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        SET_HIP(hipStreamSynchronize(ctx->stream));
+        s->scale8.assign(n_images, 1.0f);
+        s->l1max.assign(n_images, 0.0f);
+        for (int i = 0; i < n_images; i++) {
+            float mx, l1;
+            memcpy(&mx, &stats[2 * i], 4);
+            memcpy(&l1, &stats[2 * i + 1], 4);
+            s->scale8[i] = (mx > 0.0f) ? 127.0f / mx : 1.0f;
+            s->l1max[i] = l1;
+            memcpy(&s->images[i].pad, &s->scale8[i], 4);
+        }
+        SET_HIP(hipMemcpyAsync(s->imageRecs.p, s->images.data(), (size_t)n_images * sizeof(ImageRec),
+                               hipMemcpyHostToDevice, ctx->stream));
+        dim3 g3(((int64_t)maxN * 8 + 255) / 256, n_images);
+        hipLaunchKernelGGL(ingest_i8_kernel, g3, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
+                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->desc8.as<signed char>());
+        SET_HIP(hipGetLastError());
+    }
+    if (s->scale8.empty()) {
+        s->scale8.assign(n_images, 1.0f);
+        s->l1max.assign(n_images, 0.0f);
     }
     SET_HIP(hipStreamSynchronize(ctx->stream));
 #undef SET_HIP
@@ -1118,6 +1297,22 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 r.thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN;
             else
                 r.thr_m = (thrp == 0.0f) ? -SIM_MARGIN : 0.0f; // DOT with a positive bound tests per cell
+            // Bound on the int8 dot product S = sum q_k p_k, q = round(a_hat * sA), p = round(b_hat * sB):
+            // |a_hat.b_hat * sA * sB - S| <= 0.5001 (sA L1_A + sB L1_B) + 0.7505 dim  (rounding errors
+            // e, f with |e|, |f| <= 0.5001 against |q| <= sA |a_hat| + 0.5001), and the reference's cosine
+            // is within 1e-4 of a_hat.b_hat.
+            {
+                const double sA = set->scale8[ia], sB = set->scale8[ib];
+                const double err = 0.5001 * (sA * set->l1max[ia] + sB * set->l1max[ib]) + 0.7505 * set->dim;
+                const double t = ((double)thrp - 1e-4) * sA * sB - err;
+                if (threshold != threshold)
+                    r.thr_i = INT_MAX;
+                else if (wild || metric != SFM_METRIC_COSINE || !(t > -1e9))
+                    r.thr_i = -(1 << 30);
+                else
+                    r.thr_i = (int32_t)std::floor(std::min(t, 2.0e9));
+            }
+            r.pad_ = 0;
             outTotalCap += std::min(A.n, B.n);
             maxNA = std::max(maxNA, A.n);
             maxNB = std::max(maxNB, B.n);
@@ -1169,7 +1364,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->best.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(u64)));
     SFM_HIP(ctx, res->ovfList.reserve((size_t)(chunkPairs + 1) * sizeof(int)));
     SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
-    SFM_HIP(ctx, res->stats.reserve(2 * sizeof(u64)));
+    SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
     if (want_m1m2) {
         SFM_HIP(ctx, res->m1.reserve((size_t)(maxNA ? maxNA : 1) * sizeof(int32_t)));
         SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
@@ -1180,10 +1375,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     if (workTotal > 0)
         SFM_HIP(ctx, hipMemcpyAsync(res->work.p, work, (size_t)workTotal * sizeof(int2), hipMemcpyHostToDevice, st));
     SFM_HIP(ctx, hipMemsetAsync(res->offsets.p, 0, sizeof(int64_t), st));
-    SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 2 * sizeof(u64), st));
+    SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 4 * sizeof(u64), st));
 
     MatchArgs g;
     g.desc16 = set->desc16.as<_Float16>();
+    g.desc8 = set->desc8.as<signed char>();
     g.desc32 = set->desc32.as<float>();
     g.norms = set->norms.as<float>();
     g.pts = set->pts.as<double2>();
@@ -1224,6 +1420,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 g.onlyFlagged = 0;
                 hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(variant.threads), 0, st, g);
                 SFM_HIP(ctx, sfm_span_end(ctx, 0));
+            }
+            if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
+                g.onlyFlagged = 3;
+                hipLaunchKernelGGL(variant.strict16, dim3(nblk), dim3(variant.threads), 0, st, g);
             }
             // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
             // orientations.  Dot: every pair takes this path.
@@ -1383,4 +1583,15 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
     sfm_match_result_destroy(res);
     sfm_imageset_destroy(set);
     return rc;
+}
+
+extern "C" int sfm_match_result_stats_ex(sfm_match_result *res, int64_t *stats4_out)
+{
+    if (!res || !stats4_out) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = res->ctx;
+    u64 s[4] = {0, 0, 0, 0};
+    SFM_HIP(ctx, hipMemcpyAsync(s, res->stats.p, sizeof s, hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; i++) stats4_out[i] = (int64_t)s[i];
+    return SFM_OK;
 }

@@ -10,7 +10,9 @@ struct PairRec {
     int64_t rowA16, rowB16; // first row in desc16
     int64_t bestRow, bestCol; // first slot in the best[] array of the chunk
     float thr_m;            // candidate bound on the approximate cosine
+    int32_t thr_i;          // the same bound on the int8 dot product (instances that use the int8 table)
     int32_t chunkLocal;     // index inside the chunk
+    int32_t pad_;
 };
 
 struct ImageRec {
@@ -27,7 +29,9 @@ struct sfm_imageset {
     std::vector<ImageRec> images;
     std::vector<int> flags;
     int64_t rows32 = 0, rows16 = 0;
-    DevBuf desc32, desc16, norms, pts, imageRecs, imageFlags;
+    DevBuf desc32, desc16, desc8, norms, pts, imageRecs, imageFlags, imageStats;
+    std::vector<float> scale8; // per image: int8 value = round(unit-normalised element * scale8)
+    std::vector<float> l1max;  // per image: largest L1 norm of a unit-normalised descriptor
     bool owns_desc32 = true, owns_pts = true;
 };
 
