@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     constexpr int DMA = BN_ * ROWB / 1024 / WAVES; // LDS-DMA instructions per wave per step
     static_assert(BN_ * ROWB % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
     static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers");
-    static_assert(!I8 || (!GENERAL && !DOT && !PIPE), "the int8 bound has a strict cosine instance only");
+    static_assert(!I8 || (!GENERAL && !DOT), "the int8 bound has a strict cosine instance only");
     __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * ROWB];
     // general instance: positions of the block's rows, of the staged columns, and the row bounds
     constexpr int BLOCK_ROWS = WAVES * RT * 32;
@@ -778,8 +778,9 @@ struct SimVariant {
      match_sim_kernel<RT, WAVES, BN_, 2, 0, true, ABL, 2, MF16, true>,                                          \
      "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL "_st" #STAGES "_mf16" #MF16}
 // int8 bound for the strict pass; the general and dot instances are the fp16 ones of the same geometry
-#define SIM_VARIANT_I8(RT, WAVES, BN_, OCC, ABL, STAGES)                                                      \
-    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, 0, false, ABL, STAGES, 3, false>,      \
+#define SIM_VARIANT_I8(RT, WAVES, BN_, OCC, ABL, STAGES) SIM_VARIANT_I8P(RT, WAVES, BN_, OCC, 0, ABL, STAGES)
+#define SIM_VARIANT_I8P(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES)                                               \
+    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, 3, false>,   \
      match_sim_kernel<RT, WAVES, 64, 4, 0, false, 0, 2, 1, false>,                                            \
      match_sim_kernel<RT, WAVES, 64, 2, 0, false, 0, 2, 1, true>,                                             \
      match_sim_kernel<RT, WAVES, 64, 2, 0, true, 0, 2, 1, true>,                                              \
