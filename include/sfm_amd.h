@@ -107,6 +107,11 @@ int sfm_match_pair(sfm_ctx *ctx, int algorithm,
 int sfm_imageset_create(sfm_ctx *ctx, int n_images, const int32_t *counts,
                         const float *desc, const double *pts, int dim,
                         sfm_imageset **set_out);
+/* The same from byte-valued descriptors (SIFT as OpenCV quantises it,
+ * detectOpenCv.cpp:166-169: integers 0..255), desc[rows][dim] uint8: a quarter
+ * of the upload; results are those of the float table holding the same values. */
+int sfm_imageset_create_u8(sfm_ctx *ctx, int n_images, const int32_t *counts, const uint8_t *desc,
+                           const double *pts, int dim, sfm_imageset **set_out);
 /* Same, with desc/pts already in device memory of ctx's device. */
 int sfm_imageset_create_device(sfm_ctx *ctx, int n_images, const int32_t *counts,
                                const float *desc_device, const double *pts_device, int dim,

@@ -25,7 +25,7 @@ _STATUS_NAMES = {1: "invalid argument", 2: "no gfx950 device", 3: "out of memory
 EXPORTED_SYMBOLS = [
     "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_synchronize", "sfm_last_error", "sfm_version",
     "sfm_ctx_set_option", "sfm_ctx_last_kernel_ms",
-    "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_device", "sfm_imageset_destroy",
+    "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_u8", "sfm_imageset_create_device", "sfm_imageset_destroy",
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
     "sfm_match_result_destroy",
@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
     L.sfm_match_pair.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, i32, P(i32), vp, vp]
     L.sfm_imageset_create.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
     L.sfm_imageset_create_device.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
+    L.sfm_imageset_create_u8.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
     L.sfm_imageset_destroy.argtypes = [vp]
     L.sfm_imageset_destroy.restype = None
     L.sfm_imageset_device_bytes.argtypes = [vp]
@@ -252,7 +253,14 @@ class ImageSet:
         counts = np.ascontiguousarray(counts, np.int32)
         self._h = C.c_void_p()
         self.n_images = len(counts)
-        if isinstance(desc, np.ndarray):
+        if isinstance(desc, np.ndarray) and desc.dtype == np.uint8:
+            desc = np.ascontiguousarray(desc)
+            pts = np.ascontiguousarray(pts, np.float64)
+            if dim is None:
+                dim = desc.shape[-1]
+            ctx.check(lib().sfm_imageset_create_u8(ctx._h, len(counts), _ptr(counts), _ptr(desc), _ptr(pts), dim,
+                                                   C.byref(self._h)))
+        elif isinstance(desc, np.ndarray):
             desc = np.ascontiguousarray(desc, np.float32)
             pts = np.ascontiguousarray(pts, np.float64)
             if dim is None:

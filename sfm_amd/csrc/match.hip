@@ -43,10 +43,12 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 // flags per image
 #define IMG_WILD_COS 1 // a descriptor norm outside [1e-12, 1e12] (and not 0/inf/nan)
 #define IMG_WILD_DOT 2 // a descriptor norm that is 0, non-finite or outside that range
+#define IMG_NOT_U8 4   // an element that is not an integer in [0, 255]
 
 struct MatchArgs {
     const _Float16 *desc16;
     const signed char *desc8; // unit-normalised descriptors quantised to int8, 128 bytes per row
+    const unsigned char *desc8u; // byte copy of desc32 (dim 128, rows as desc32) when every element is an integer in [0, 255], else null
     const float *desc32;
     const float *norms;
     const double2 *pts;
@@ -83,11 +85,15 @@ __global__ void ingest_norm_kernel(const float *__restrict__ desc32, const Image
     if (r >= im.n) return;
     const float *a = desc32 + (size_t)(im.row32 + r) * dim;
     float normA = 0.0f;
-    for (int k = 0; k < dim; k++) normA = __fadd_rn(normA, __fmul_rn(a[k], a[k]));
+    bool bytes = true;
+    for (int k = 0; k < dim; k++) {
+        normA = __fadd_rn(normA, __fmul_rn(a[k], a[k]));
+        bytes = bytes && a[k] >= 0.0f && a[k] <= 255.0f && a[k] == floorf(a[k]);
+    }
     const float s = __fsqrt_rn(normA);
     norms[im.row32 + r] = s;
     const bool inRange = (s >= 1e-12f) && (s <= 1e12f);
-    int f = 0;
+    int f = bytes ? 0 : IMG_NOT_U8;
     if (!inRange) {
         f |= IMG_WILD_DOT;
         if (s != 0.0f && s == s && s != INFINITY) f |= IMG_WILD_COS;
@@ -116,6 +122,30 @@ __global__ void ingest_f16_kernel(const float *__restrict__ desc32, const ImageR
         out[e] = (_Float16)v;
     }
     *reinterpret_cast<half8 *>(desc16 + (size_t)(im.row16 + r) * KDIM + k0) = out;
+}
+
+// Byte copy of a table whose elements are all integers in [0, 255] (SIFT descriptors as OpenCV
+// delivers them, detectOpenCv.cpp:166-169): the exact pass then reads a quarter of the bytes and
+// computes the same fp32 values.  One thread per 16 elements.
+__global__ void ingest_u8_kernel(const float *__restrict__ desc32, int64_t rows, unsigned char *__restrict__ desc8u)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * 8) return;
+    const float4 *src = reinterpret_cast<const float4 *>(desc32 + t * 16);
+    int4v out;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float4 v = src[w];
+        out[w] = (int)((unsigned)v.x | ((unsigned)v.y << 8) | ((unsigned)v.z << 16) | ((unsigned)v.w << 24));
+    }
+    *reinterpret_cast<int4v *>(desc8u + t * 16) = out;
+}
+
+// The other direction, for tables handed over as bytes.
+__global__ void expand_u8_kernel(const unsigned char *__restrict__ src, int64_t n, float *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = (float)src[t];
 }
 
 // Per image, over its unit-normalised descriptors a / |a|: the largest |element| and the largest L1
@@ -848,7 +878,7 @@ __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
 // index order.  Candidates of a pair are numbered across its slices with a prefix sum so that
 // waves are full.
 #define CAND_ROWB 272 // LDS bytes per candidate per step: 2 x 128 B of data + 16 B pad (bank spread)
-__global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
+template <bool U8> __global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
 {
     __shared__ int prefix[1025];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][64 * CAND_ROWB];
@@ -900,6 +930,41 @@ __global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         float dot = 0.0f;
+        if constexpr (U8) { // whole rows are 128 B: one round, bytes widened on the fly (exact)
+            const unsigned char *A8 = g.desc8u + (size_t)pr.rowA32 * 128;
+            const unsigned char *B8 = g.desc8u + (size_t)pr.rowB32 * 128;
+            uint4 v[16];
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int rc = it * 8 + (lane >> 3);
+                const uint2 who = ij[wave][rc >> 1];
+                const unsigned char *src = (rc & 1) ? B8 + (size_t)who.y * 128 : A8 + (size_t)who.x * 128;
+                v[it] = *reinterpret_cast<const uint4 *>(src + (lane & 7) * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int rc = it * 8 + (lane >> 3);
+                *reinterpret_cast<uint4 *>(st + (rc >> 1) * CAND_ROWB + (rc & 1) * 128 + (lane & 7) * 16) = v[it];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint4 *ma = reinterpret_cast<const uint4 *>(st + lane * CAND_ROWB);
+            const uint4 *mb = reinterpret_cast<const uint4 *>(st + lane * CAND_ROWB + 128);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint4 av = ma[e], bv = mb[e];
+                const unsigned aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        dot = __fadd_rn(dot, __fmul_rn((float)((aw[w] >> (8 * b)) & 0xFFu), (float)((bw[w] >> (8 * b)) & 0xFFu)));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else
         for (int kc = 0; kc < 4; kc++) {
             float4 v[16];
 #pragma unroll
@@ -1065,6 +1130,7 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
     if (s->owns_desc32) s->desc32.release();
     s->desc16.release();
     s->desc8.release();
+    s->desc8u.release();
     s->imageStats.release();
     s->norms.release();
     if (s->owns_pts) s->pts.release();
@@ -1076,11 +1142,12 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
 extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
 {
     if (!s) return 0;
-    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
+    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->desc8u.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
 }
 
 static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, const float *desc,
-                          const double *pts, int dim, bool on_device, sfm_imageset **set_out)
+                          const double *pts, int dim, bool on_device, sfm_imageset **set_out,
+                          const unsigned char *desc_bytes = nullptr)
 {
     if (!ctx || !set_out) return SFM_ERR_INVALID_ARG;
     *set_out = nullptr;
@@ -1113,7 +1180,7 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     // one extra padded block so that a B tile or an A block may read past the last image
     r16 += ROW_PAD;
     s->rows16 = r16;
-    if (r32 > 0 && (!desc || !pts)) {
+    if (r32 > 0 && ((!desc && !desc_bytes) || !pts)) {
         delete s;
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: null descriptor or point table");
     }
@@ -1138,7 +1205,17 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     } else {
         SET_HIP(s->desc32.reserve(b32 ? b32 : 16));
         SET_HIP(s->pts.reserve(bpts ? bpts : 16));
-        if (b32) SET_HIP(hipMemcpyAsync(s->desc32.p, desc, b32, hipMemcpyHostToDevice, ctx->stream));
+        if (b32 && desc_bytes) { // byte table: a quarter of the upload, widened on the device
+            DevBuf tmp;
+            SET_HIP(tmp.reserve((size_t)r32 * dim));
+            SET_HIP(hipMemcpyAsync(tmp.p, desc_bytes, (size_t)r32 * dim, hipMemcpyHostToDevice, ctx->stream));
+            const int64_t n = r32 * dim;
+            hipLaunchKernelGGL(expand_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const unsigned char *)tmp.p, n, s->desc32.as<float>());
+            SET_HIP(hipStreamSynchronize(ctx->stream));
+            tmp.release();
+        } else if (b32)
+            SET_HIP(hipMemcpyAsync(s->desc32.p, desc, b32, hipMemcpyHostToDevice, ctx->stream));
         if (bpts) SET_HIP(hipMemcpyAsync(s->pts.p, pts, bpts, hipMemcpyHostToDevice, ctx->stream));
     }
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
@@ -1164,6 +1241,7 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         SET_HIP(hipGetLastError());
         SET_HIP(hipMemcpyAsync(s->flags.data(), s->imageFlags.p, (size_t)n_images * sizeof(int),
                                hipMemcpyDeviceToHost, ctx->stream));
+        // (flags arrive with the synchronisation below)
         // int8 table: per-image scale from the largest unit-normalised element
         hipLaunchKernelGGL(ingest_stats_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
                            s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>());
@@ -1188,6 +1266,15 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
                            s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->desc8.as<signed char>());
         SET_HIP(hipGetLastError());
     }
+    // byte copy for the exact pass when the whole table is byte-valued
+    s->u8_exact = dim == 128 && r32 > 0;
+    for (int i = 0; i < n_images; i++) s->u8_exact = s->u8_exact && !(s->flags[i] & IMG_NOT_U8);
+    if (s->u8_exact) {
+        SET_HIP(s->desc8u.reserve((size_t)r32 * 128));
+        hipLaunchKernelGGL(ingest_u8_kernel, dim3((unsigned)((r32 * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
+                           s->desc32.as<float>(), r32, s->desc8u.as<unsigned char>());
+        SET_HIP(hipGetLastError());
+    }
     if (s->scale8.empty()) {
         s->scale8.assign(n_images, 1.0f);
         s->l1max.assign(n_images, 0.0f);
@@ -1202,6 +1289,12 @@ extern "C" int sfm_imageset_create(sfm_ctx *ctx, int n_images, const int32_t *co
                                    const double *pts, int dim, sfm_imageset **set_out)
 {
     return imageset_build(ctx, n_images, counts, desc, pts, dim, false, set_out);
+}
+
+extern "C" int sfm_imageset_create_u8(sfm_ctx *ctx, int n_images, const int32_t *counts, const uint8_t *desc,
+                                      const double *pts, int dim, sfm_imageset **set_out)
+{
+    return imageset_build(ctx, n_images, counts, nullptr, pts, dim, false, set_out, desc);
 }
 
 extern "C" int sfm_imageset_create_device(sfm_ctx *ctx, int n_images, const int32_t *counts,
@@ -1381,6 +1474,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     MatchArgs g;
     g.desc16 = set->desc16.as<_Float16>();
     g.desc8 = set->desc8.as<signed char>();
+    g.desc8u = set->u8_exact ? set->desc8u.as<unsigned char>() : nullptr;
     g.desc32 = set->desc32.as<float>();
     g.norms = set->norms.as<float>();
     g.pts = set->pts.as<double2>();
@@ -1442,7 +1536,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             g.work = workList[0];
             if (candCap > 0) {
                 if (set->dim == 128 && maxQueues <= 1024)
-                    hipLaunchKernelGGL(match_cand128_kernel, dim3(4, np), dim3(256), 0, st, g);
+                    hipLaunchKernelGGL(g.desc8u ? match_cand128_kernel<true> : match_cand128_kernel<false>, dim3(4, np),
+                                       dim3(256), 0, st, g);
                 else
                     hipLaunchKernelGGL(match_cand_kernel, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
             }

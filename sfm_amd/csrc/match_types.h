@@ -29,10 +29,11 @@ struct sfm_imageset {
     std::vector<ImageRec> images;
     std::vector<int> flags;
     int64_t rows32 = 0, rows16 = 0;
-    DevBuf desc32, desc16, desc8, norms, pts, imageRecs, imageFlags, imageStats;
+    DevBuf desc32, desc16, desc8, desc8u, norms, pts, imageRecs, imageFlags, imageStats;
     std::vector<float> scale8; // per image: int8 value = round(unit-normalised element * scale8)
     std::vector<float> l1max;  // per image: largest L1 norm of a unit-normalised descriptor
     bool owns_desc32 = true, owns_pts = true;
+    bool u8_exact = false;     // desc8u holds a byte copy of desc32 (every element an integer in [0, 255], dim 128)
 };
 
 struct sfm_match_result {

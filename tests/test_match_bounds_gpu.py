@@ -74,3 +74,34 @@ def test_int8_flood_is_redone_with_the_fp16_bound(ctx, oracle):
         ctx.set_option("cand_capacity", 524288)
     assert m >= 300 and cells == 0 and filtered == 0 and redone == 1
     assert cand < 65536
+
+
+def test_byte_table_equals_float_table(ctx, oracle):
+    """sfm_imageset_create_u8 (bytes in) against the float table holding the same values and against the
+    restatement; a table with one non-integer element takes the fp32 exact pass and agrees too."""
+    ctx.set_option("sim_variant", INT8_BOUND)
+    counts = np.array([900, 0, 1300, 700], np.int32)
+    n = int(counts.max())
+    d, p, _ = synth.image_set(len(counts), n, seed=91)
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)])
+    assert np.array_equal(desc, desc.astype(np.uint8).astype(np.float32))
+    pl = np.array([[0, 2], [2, 3], [3, 0], [1, 2], [2, 2]], np.int32)
+    sf = ctx.imageset(counts, desc, pts)
+    sb = ctx.imageset(counts, desc.astype(np.uint8), pts)
+    desc2 = desc.copy()
+    desc2[5, 7] += 0.5  # no longer byte-valued: fp32 rows in the exact pass
+    sx = ctx.imageset(counts, desc2, pts)
+    rf, rb, rx = (s.match(pl, threshold=0.9, max_dist_sq=300.0 ** 2) for s in (sf, sb, sx))
+    assert np.array_equal(rf.offsets(), rb.offsets()) and np.array_equal(rf.pairs(), rb.pairs())
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    off, pairs = rf.offsets(), rf.pairs()
+    offx, pairsx = rx.offsets(), rx.pairs()
+    for k, (a, b) in enumerate(pl):
+        A, B = slice(starts[a], starts[a + 1]), slice(starts[b], starts[b + 1])
+        exp, _, _ = oracle.match(desc[A], pts[A], desc[B], pts[B], threshold=0.9, max_dist_sq=300.0 ** 2)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp)
+        exp2, _, _ = oracle.match(desc2[A], pts[A], desc2[B], pts[B], threshold=0.9, max_dist_sq=300.0 ** 2)
+        assert np.array_equal(pairsx[offx[k]:offx[k + 1]], exp2)
+    for s in (sf, sb, sx):
+        s.close()
