@@ -1338,6 +1338,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         *result_inout = res;
     } else if (res->ctx != ctx) {
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: result belongs to another context");
+    } else {
+        // the staging buffers of a reused result may still be the source of copies in flight
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     res->n_pairs = n_pairs;
     res->total = -1;
@@ -1348,7 +1351,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     const int chunkPairs = (int)std::min<int64_t>(ctx->pairs_per_launch, n_pairs > 0 ? n_pairs : 1);
     const int candCap = (int)ctx->cand_capacity;
 
-    // --- host records -------------------------------------------------------------------
+    // --- sizes ------------------------------------------------------------------------------
+    // The records and work lists themselves are written chunk by chunk further down, each chunk
+    // right before its launches, so that the device is busy while the host prepares the next one.
     SFM_HIP(ctx, res->hostRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
     PairRec *recs = res->hostRecs.as<PairRec>();
     int64_t outTotalCap = 0, maxBest = 0;
@@ -1359,17 +1364,44 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     int64_t workTotal = 0;
     int maxNA = 0, maxNB = 0;
     const int wavesPerBlock = variant.threads / 64;
-    auto row_blocks = [&](const PairRec &r, int orient) {
-        if (r.nA <= 0 || r.nB <= 0) return 0;
-        return ((orient ? r.nB : r.nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
+    auto row_blocks = [&](int nA, int nB, int orient) {
+        if (nA <= 0 || nB <= 0) return 0;
+        return ((orient ? nB : nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
     };
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
         int64_t bestOff = 0;
+        int64_t queueLen[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
         for (int p = c0; p < c1; p++) {
             const int ia = pair_list[2 * p], ib = pair_list[2 * p + 1];
             if (ia < 0 || ia >= set->n_images || ib < 0 || ib >= set->n_images)
                 SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: pair %d names image %d/%d outside the set", p, ia, ib);
+            const int nA = set->images[ia].n, nB = set->images[ib].n;
+            bestOff += (int64_t)nA + nB;
+            outTotalCap += std::min(nA, nB);
+            maxNA = std::max(maxNA, nA);
+            maxNB = std::max(maxNB, nB);
+            for (int o = 0; o < 2; o++) queueLen[o][(p - c0) & 7] += row_blocks(nA, nB, o);
+        }
+        maxBest = std::max(maxBest, bestOff);
+        for (int o = 0; o < 2; o++) {
+            int64_t qmax = 0;
+            for (int x = 0; x < 8; x++) qmax = std::max(qmax, queueLen[o][x]);
+            chunkWorkBase[o].push_back(workTotal);
+            chunkWorkCount[o].push_back((int)(qmax * 8));
+            workTotal += qmax * 8;
+        }
+    }
+    SFM_HIP(ctx, res->hostWork.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
+    int2 *work = res->hostWork.as<int2>();
+
+    // Records of one chunk, and its work lists: block b of a chunk takes entry b.  Blocks b and
+    // b + 8 run on the same XCD (round-robin dispatch), so every pair's row blocks are dealt to one
+    // residue class mod 8 and share that XCD's L2 copy of the streamed image.
+    auto prepare_chunk = [&](int c0, int c1, size_t ci) {
+        int64_t bestOff = 0;
+        for (int p = c0; p < c1; p++) {
+            const int ia = pair_list[2 * p], ib = pair_list[2 * p + 1];
             const ImageRec &A = set->images[ia], &B = set->images[ib];
             PairRec &r = recs[p];
             r.nA = A.n;
@@ -1395,56 +1427,29 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             // |a_hat.b_hat * sA * sB - S| <= 0.5001 (sA L1_A + sB L1_B) + 0.7505 dim  (rounding errors
             // e, f with |e|, |f| <= 0.5001 against |q| <= sA |a_hat| + 0.5001), and the reference's cosine
             // is within 1e-4 of a_hat.b_hat.
-            {
-                const double sA = set->scale8[ia], sB = set->scale8[ib];
-                const double err = 0.5001 * (sA * set->l1max[ia] + sB * set->l1max[ib]) + 0.7505 * set->dim;
-                const double t = ((double)thrp - 1e-4) * sA * sB - err;
-                if (threshold != threshold)
-                    r.thr_i = INT_MAX;
-                else if (wild || metric != SFM_METRIC_COSINE || !(t > -1e9))
-                    r.thr_i = -(1 << 30);
-                else
-                    r.thr_i = (int32_t)std::floor(std::min(t, 2.0e9));
-            }
+            const double sA = set->scale8[ia], sB = set->scale8[ib];
+            const double err = 0.5001 * (sA * set->l1max[ia] + sB * set->l1max[ib]) + 0.7505 * set->dim;
+            const double t = ((double)thrp - 1e-4) * sA * sB - err;
+            if (threshold != threshold)
+                r.thr_i = INT_MAX;
+            else if (wild || metric != SFM_METRIC_COSINE || !(t > -1e9))
+                r.thr_i = -(1 << 30);
+            else
+                r.thr_i = (int32_t)std::floor(std::min(t, 2.0e9));
             r.pad_ = 0;
-            outTotalCap += std::min(A.n, B.n);
-            maxNA = std::max(maxNA, A.n);
-            maxNB = std::max(maxNB, B.n);
         }
-        maxBest = std::max(maxBest, bestOff);
         for (int o = 0; o < 2; o++) {
-            int64_t queueLen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int p = c0; p < c1; p++) queueLen[(p - c0) & 7] += row_blocks(recs[p], o);
-            int64_t qmax = 0;
-            for (int x = 0; x < 8; x++) qmax = std::max(qmax, queueLen[x]);
-            chunkWorkBase[o].push_back(workTotal);
-            chunkWorkCount[o].push_back((int)(qmax * 8));
-            workTotal += qmax * 8;
-        }
-    }
-
-    // Work list: block b of a chunk takes entry b.  Blocks b and b + 8 run on the same XCD
-    // (round-robin dispatch), so every pair's row blocks are dealt to one residue class mod 8
-    // and share that XCD's L2 copy of the streamed image.
-    SFM_HIP(ctx, res->hostWork.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
-    int2 *work = res->hostWork.as<int2>();
-    {
-        size_t ci = 0;
-        for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
-            const int c1 = std::min(n_pairs, c0 + chunkPairs);
-            for (int o = 0; o < 2; o++) {
-                int2 *wl = work + chunkWorkBase[o][ci];
-                const int cnt = chunkWorkCount[o][ci];
-                for (int k = 0; k < cnt; k++) wl[k] = make_int2(-1, 0);
-                int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int p = c0; p < c1; p++) {
-                    const int x = (p - c0) & 7;
-                    const int nb = row_blocks(recs[p], o);
-                    for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb);
-                }
+            int2 *wl = work + chunkWorkBase[o][ci];
+            const int cnt = chunkWorkCount[o][ci];
+            for (int k = 0; k < cnt; k++) wl[k] = make_int2(-1, 0);
+            int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int p = c0; p < c1; p++) {
+                const int x = (p - c0) & 7;
+                const int nb = row_blocks(recs[p].nA, recs[p].nB, o);
+                for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb);
             }
         }
-    }
+    };
 
     // --- device buffers -----------------------------------------------------------------
     SFM_HIP(ctx, res->pairRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
@@ -1464,10 +1469,6 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
     }
     hipStream_t st = ctx->stream;
-    if (n_pairs > 0)
-        SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.p, recs, (size_t)n_pairs * sizeof(PairRec), hipMemcpyHostToDevice, st));
-    if (workTotal > 0)
-        SFM_HIP(ctx, hipMemcpyAsync(res->work.p, work, (size_t)workTotal * sizeof(int2), hipMemcpyHostToDevice, st));
     SFM_HIP(ctx, hipMemsetAsync(res->offsets.p, 0, sizeof(int64_t), st));
     SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 4 * sizeof(u64), st));
 
@@ -1497,6 +1498,15 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
         const int np = c1 - c0;
+        prepare_chunk(c0, c1, ci);
+        SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.as<PairRec>() + c0, recs + c0, (size_t)np * sizeof(PairRec),
+                                    hipMemcpyHostToDevice, st));
+        {
+            const int64_t w0 = chunkWorkBase[0][ci], wn = (int64_t)chunkWorkCount[0][ci] + chunkWorkCount[1][ci];
+            if (wn > 0)
+                SFM_HIP(ctx, hipMemcpyAsync(res->work.as<int2>() + w0, work + w0, (size_t)wn * sizeof(int2),
+                                            hipMemcpyHostToDevice, st));
+        }
         g.pairs = res->pairRecs.as<PairRec>() + c0;
         const int2 *workList[2] = {res->work.as<int2>() + chunkWorkBase[0][ci], res->work.as<int2>() + chunkWorkBase[1][ci]};
         g.work = workList[0];
