@@ -86,39 +86,54 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    res = None
+    # Two result objects: at N > 1 the gather of step k - 1 (RCCL, torch's streams) runs while the
+    # library's stream matches step k.  Every gather is finished before the closing barrier.
+    results = [None, None]
     gathered = None
+    res = None
 
-    def step():
-        nonlocal res, gathered
-        res = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=res)
-        if world > 1:
-            total = res.total()  # synchronises the library's stream
-            optr, pptr = res.device_ptrs()
-            dev = torch.device(f"cuda:{local_rank}")
-            off_t = torch.as_tensor(shard.DevicePtrView(optr, (len(my_pairs) + 1,), "<i8"), device=dev)
-            cnt_t = off_t[1:] - off_t[:-1]
-            pay_t = torch.as_tensor(shard.DevicePtrView(pptr, (max(total, 1), 2), "<i4"), device=dev)[:total]
-            gathered = shard.gather_csr(cnt_t, pay_t, total_pairs, rank, world)
-        else:
+    def launch(k):
+        results[k & 1] = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=results[k & 1])
+        return results[k & 1]
+
+    def gather(r):
+        nonlocal gathered
+        total = r.total()  # cached when its step finished
+        optr, pptr = r.device_ptrs()
+        dev = torch.device(f"cuda:{local_rank}")
+        off_t = torch.as_tensor(shard.DevicePtrView(optr, (len(my_pairs) + 1,), "<i8"), device=dev)
+        cnt_t = off_t[1:] - off_t[:-1]
+        pay_t = torch.as_tensor(shard.DevicePtrView(pptr, (max(total, 1), 2), "<i4"), device=dev)[:total]
+        gathered = shard.gather_csr(cnt_t, pay_t, total_pairs, rank, world, ordered=False)
+
+    def run(n_steps):
+        """n_steps matcher passes, each followed (at N > 1) by the gather of its match lists to rank 0."""
+        nonlocal res
+        ms, nl = 0.0, 0
+        prev = None
+        for k in range(n_steps):
+            res = launch(k)
+            if world > 1 and prev is not None:
+                gather(prev)
             ctx.synchronize()
+            if world > 1:
+                torch.cuda.synchronize()  # the gather reads prev's buffers, which step k + 1 overwrites
+                res.total()               # cached: gather() must not wait on the library's stream later
+            a, b = ctx.last_kernel_ms(0)
+            ms, nl = ms + a, nl + b
+            prev = res
+        if world > 1 and prev is not None:
+            gather(prev)
+            torch.cuda.synchronize()
+        return ms, nl
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     barrier()
-    kernel_ms, kernel_launches = 0.0, 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if world == 1:
-            ms, nl = ctx.last_kernel_ms(0)
-            kernel_ms += ms
-            kernel_launches += nl
+    kernel_ms, kernel_launches = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        ms, nl = ctx.last_kernel_ms(0)
-        kernel_ms, kernel_launches = ms * args.steps, nl * args.steps
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

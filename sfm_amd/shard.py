@@ -42,22 +42,26 @@ class DevicePtrView:
 
 
 def gather_csr(counts, payload, n_pairs_total: int, rank: int, world: int, block: int = 64,
-               width: int = 2, device=None) -> Optional[Tuple[np.ndarray, "object"]]:
+               width: int = 2, device=None, ordered: bool = True) -> Optional[Tuple[np.ndarray, ...]]:
     """Gather per-rank CSR lists to rank 0.
 
     counts: torch int64 tensor [owned pairs] (entries per owned pair, on `device`);
     payload: torch int32 tensor [sum(counts), width] on `device`.
-    Returns on rank 0 (offsets int64 numpy [n_pairs_total+1], payload tensor in global pair
-    order); None elsewhere.  Uses torch.distributed send/recv (RCCL over xGMI with the nccl
-    backend: rank 0 posts all receives at once, one per peer link)."""
+    Returns None on ranks other than 0.  On rank 0:
+      ordered=True:  (offsets int64 numpy [n_pairs_total+1], payload tensor in global pair order);
+      ordered=False: (starts int64 numpy [n_pairs_total], counts int64 numpy [n_pairs_total], payload
+                     tensor laid out rank after rank): pair p owns payload[starts[p] : starts[p] + counts[p]].
+                     Every peer's list is received straight into its place, nothing is copied twice.
+    Uses torch.distributed send/recv (RCCL over xGMI with the nccl backend: rank 0 posts all
+    receives at once, one per peer link)."""
     import torch
     import torch.distributed as dist
 
     if world <= 1:
-        c = counts.cpu().numpy()
+        c = counts.cpu().numpy().astype(np.int64)
         off = np.zeros(n_pairs_total + 1, np.int64)
         np.cumsum(c, out=off[1:])
-        return off, payload
+        return (off, payload) if ordered else (off[:-1].copy(), c, payload)
 
     owned = [partition_pairs(n_pairs_total, r, world, block) for r in range(world)]
     max_owned = max(len(o) for o in owned)
@@ -66,40 +70,46 @@ def gather_csr(counts, payload, n_pairs_total: int, rank: int, world: int, block
     mine[:len(counts)] = counts
     all_counts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(all_counts, mine)
-    # step 2: payloads to rank 0, all peers at once
+    # step 2: payloads to rank 0, all peers at once, each into its region of one buffer
     if rank != 0:
         if payload.numel() > 0:
             dist.send(payload.contiguous(), dst=0)
         return None
-    per_rank_counts = [all_counts[r][:len(owned[r])].cpu().numpy() for r in range(world)]
-    bufs, ops = [payload], []
+    per_rank_counts = [all_counts[r][:len(owned[r])].cpu().numpy().astype(np.int64) for r in range(world)]
+    totals = [int(c.sum()) for c in per_rank_counts]
+    base = np.concatenate([[0], np.cumsum(totals)]).astype(np.int64)
+    gathered = torch.empty((int(base[-1]), width), dtype=payload.dtype, device=payload.device)
+    if totals[0] > 0:
+        gathered[:totals[0]] = payload
+    ops = []
     for r in range(1, world):
-        tot = int(per_rank_counts[r].sum())
-        buf = torch.empty((tot, width), dtype=payload.dtype, device=payload.device)
-        bufs.append(buf)
-        if tot > 0:
-            ops.append(dist.P2POp(dist.irecv, buf, r))
+        if totals[r] > 0:
+            ops.append(dist.P2POp(dist.irecv, gathered[int(base[r]):int(base[r + 1])], r))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    # step 3: global CSR in pair order
     global_counts = np.zeros(n_pairs_total, np.int64)
+    starts = np.zeros(n_pairs_total, np.int64)
     for r in range(world):
         global_counts[owned[r]] = per_rank_counts[r]
+        if len(owned[r]):
+            starts[owned[r]] = base[r] + np.concatenate([[0], np.cumsum(per_rank_counts[r])[:-1]])
+    if not ordered:
+        return starts, global_counts, gathered
+    # step 3: global CSR in pair order
     off = np.zeros(n_pairs_total + 1, np.int64)
     np.cumsum(global_counts, out=off[1:])
-    out = torch.empty((int(off[-1]), width), dtype=payload.dtype, device=payload.device)
+    out = torch.empty_like(gathered)
     for r in range(world):
         if len(owned[r]) == 0:
             continue
-        src_off = np.zeros(len(owned[r]) + 1, np.int64)
-        np.cumsum(per_rank_counts[r], out=src_off[1:])
         # consecutive owned pairs of one block are contiguous on both sides: copy block-wise
-        starts = np.flatnonzero(np.diff(np.concatenate([[-2], owned[r]])) != 1)
-        ends = np.concatenate([starts[1:], [len(owned[r])]])
-        for s, e in zip(starts, ends):
-            a, b = int(src_off[s]), int(src_off[e])
+        first = np.flatnonzero(np.diff(np.concatenate([[-2], owned[r]])) != 1)
+        last = np.concatenate([first[1:], [len(owned[r])]]) - 1
+        for s, e in zip(first, last):
+            a = int(starts[owned[r][s]])
+            b = int(starts[owned[r][e]] + global_counts[owned[r][e]])
             if b > a:
                 d0 = int(off[owned[r][s]])
-                out[d0:d0 + (b - a)] = bufs[r][a:b]
+                out[d0:d0 + (b - a)] = gathered[a:b]
     return off, out

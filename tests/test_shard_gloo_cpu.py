@@ -41,11 +41,13 @@ def _worker(rank, world, port, block, out_path):
     counts = torch.tensor([len(l) for l in lists], dtype=torch.int64)
     payload = torch.from_numpy(np.concatenate(lists).astype(np.int32) if lists else np.zeros((0, 2), np.int32))
     got = shard.gather_csr(counts, payload, len(pl), rank, world, block=block)
+    got2 = shard.gather_csr(counts, payload, len(pl), rank, world, block=block, ordered=False)
     if rank == 0:
         off, allp = got
-        np.savez(out_path, off=off, pairs=allp.numpy())
+        starts, cnts, raw = got2
+        np.savez(out_path, off=off, pairs=allp.numpy(), starts=starts, counts=cnts, raw=raw.numpy())
     else:
-        assert got is None
+        assert got is None and got2 is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,4 +68,5 @@ def test_two_rank_gather_equals_unsharded(tmp_path, oracle, block):
                            desc[b * n_feat:(b + 1) * n_feat], pts[b * n_feat:(b + 1) * n_feat],
                            threshold=0.95, max_dist_sq=1e8)[0]
         assert np.array_equal(g["pairs"][g["off"][k]:g["off"][k + 1]], exp), k
+        assert np.array_equal(g["raw"][g["starts"][k]:g["starts"][k] + g["counts"][k]], exp), k  # unordered layout
     assert g["off"][-1] == len(g["pairs"]) > 0
