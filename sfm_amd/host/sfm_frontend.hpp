@@ -5,8 +5,8 @@
 //   SfM::solve::RANSAC           (solve/solve.hpp:137, RANSAC.cpp:146-270)
 //   SfM::solve::RANSAC_OPTIONS   (solve.hpp:108-125)
 // The value types below are layout-compatible stand-ins for the Eigen typedefs of
-// submodules/SfM.hpp:8-21 (column-major doubles), so the adaptor shown in INTEGRATION.md
-// forwards Eigen's .data() pointers unchanged.  This header needs neither Eigen nor HIP.
+// submodules/SfM.hpp:8-21 (column-major doubles), so an adaptor compiled against the reference's
+// headers forwards Eigen's .data() pointers unchanged.  This header needs neither Eigen nor HIP.
 #pragma once
 #include <functional>
 #include <stdexcept>
