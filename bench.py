@@ -47,6 +47,7 @@ def main():
                     help="arithmetic of the matcher's similarity bound (the exact re-scoring is fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=3, help="8192x8192 pairs the CPU baseline matches")
     args = ap.parse_args()
 
@@ -184,6 +185,10 @@ def main():
     if not args.no_ransac:
         out["ransac"] = bench_ransac(ctx, args, rank, world, dist, local_rank)
 
+    # ---- secondary: the stages chained on the device (default-run stand-in) --------------------
+    if not args.no_pipeline and world == 1:
+        out["pipeline"] = bench_pipeline(ctx, args)
+
     # ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, desc, pts, out.get("ransac"))
@@ -205,6 +210,47 @@ def measured_traffic(pairs_per_launch, bound="int8"):
     with open(path) as f:
         t = json.load(f)
     return round(t["hbm_bytes_per_pair"] * pairs_per_launch)
+
+
+def bench_pipeline(ctx, args):
+    """Stand-in for the reference's default run (main.cpp:49-58: 27 frames, consecutive pairs, threshold
+    0.95, pixel gate 100^2, 8192 hypotheses, maxSquaredError 1, successProb 0.999) with everything
+    resident on the device: match -> normalised correspondences -> RANSAC -> refit on the inliers."""
+    from sfm_amd import capi, synth
+    frames, feats, H = 27, args.features, 8192
+    desc, pts, counts, _ = synth.frame_sequence(frames, feats, seed=4242)
+    K = synth.default_K()
+    pl = np.stack([np.arange(frames - 1), np.arange(1, frames)], axis=1).astype(np.int32)
+    s = ctx.imageset(counts, desc, pts)
+    res = corr = batch = None
+    stage_ms = np.zeros(4)
+    reps = max(1, args.steps)
+    for it in range(reps + 1):
+        t = [time.perf_counter()]
+        res = s.match(pl, threshold=0.95, max_dist_sq=100.0 * 100.0, result=res)
+        ctx.synchronize(); t.append(time.perf_counter())
+        corr = capi.Correspondences(ctx, s, res, K, reuse=corr)
+        ctx.synchronize(); t.append(time.perf_counter())
+        batch = corr.ransac(K, H, 20261111, max_sq_err=1.0, success_prob=0.999, adaptive=True, batch=batch)
+        ctx.synchronize(); t.append(time.perf_counter())
+        lib_rc = capi.lib().sfm_ransac_batch_refit(batch._h)
+        ctx.check(lib_rc)
+        ctx.synchronize(); t.append(time.perf_counter())
+        if it > 0:  # first round warms up allocations
+            stage_ms += np.diff(t) * 1e3
+    stage_ms /= reps
+    best = batch.best()
+    total = float(stage_ms.sum())
+    out = {
+        "workload": f"{frames} synthetic frames x {feats} features, {frames - 1} consecutive pairs, {H} hypotheses per pair",
+        "ms": {"match": round(stage_ms[0], 3), "correspondences": round(stage_ms[1], 3),
+               "ransac": round(stage_ms[2], 3), "refit": round(stage_ms[3], 3), "total": round(total, 3)},
+        "pairs_per_s": round((frames - 1) / (total * 1e-3), 1),
+        "matches_per_pair": round(res.total() / (frames - 1), 1),
+        "mean_inliers": float(np.mean(best["count"])),
+    }
+    s.close()
+    return out
 
 
 def bench_ransac(ctx, args, rank, world, dist, local_rank):

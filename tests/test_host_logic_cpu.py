@@ -90,3 +90,41 @@ def test_two_view_geometry_is_consistent():
     res = np.abs(np.einsum("ni,ij,nj->n", y, E, x))
     assert res[tv["inlier_mask"]].max() < 1e-9 and np.median(res[~tv["inlier_mask"]]) > 1e-3
     assert tv["inlier_mask"].sum() == 200
+
+
+def _int8_bound_holds(A, B, rng=None):
+    """Emulates the ingest of the int8 table (per-image scale from the largest unit-normalised element,
+    round to nearest) and checks the error bound the matcher's integer threshold relies on:
+    |cos * sA * sB - S| <= 0.5001 (sA L1_A + sB L1_B) + 0.7505 D for every cell."""
+    def ingest(X):
+        n = np.sqrt((X.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32)).astype(np.float32)
+        hat = (X.astype(np.float32) / n[:, None]).astype(np.float32)
+        scale = np.float32(127.0) / np.abs(hat).max()
+        q = np.rint((hat * scale).astype(np.float32)).clip(-127, 127).astype(np.int64)
+        return hat.astype(np.float64), float(scale), q, float(np.abs(hat).sum(axis=1).max() * 1.0001)
+    ha, sa, qa, l1a = ingest(A)
+    hb, sb, qb, l1b = ingest(B)
+    S = qa @ qb.T
+    cos = ha @ hb.T
+    err = 0.5001 * (sa * l1a + sb * l1b) + 0.7505 * A.shape[1]
+    worst = np.abs(cos * sa * sb - S).max()
+    assert worst <= err, (worst, err)
+    return worst / err, err / (sa * sb)
+
+
+def test_int8_bound_of_the_matcher_is_rigorous():
+    from sfm_amd import synth
+    rng = np.random.default_rng(3)
+    sift = synth.sift_like(rng, 600)
+    frac, margin = _int8_bound_holds(sift[:300], sift[300:])
+    assert margin < 0.05  # a few 1e-2 in cosine units on SIFT-like data
+    _int8_bound_holds(rng.standard_normal((300, 128)).astype(np.float32), rng.standard_normal((300, 128)).astype(np.float32))
+    # adversarial: every element sits just off a rounding boundary, all errors aligned
+    base = (np.arange(1, 129) % 7 + 0.5).astype(np.float32)
+    A = np.tile(base, (4, 1)) * np.array([[1.0], [1.0001], [0.9999], [1.00005]], np.float32)
+    _int8_bound_holds(A, A[::-1].copy())
+    # sparse and spiky descriptors (one dominant element): the scale is small, the bound must still hold
+    spiky = rng.random((200, 128)).astype(np.float32) * 0.01
+    spiky[np.arange(200), rng.integers(0, 128, 200)] = 1.0
+    _int8_bound_holds(spiky[:100], spiky[100:])
+    _int8_bound_holds(sift[:100], rng.standard_normal((100, 128)).astype(np.float32))
