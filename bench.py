@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of MI355X
 PEAK_I8_TOPS = 5000.0      # dense int8 MFMA peak: the 16x16x64 int8 form takes the cycles of the bf16 16x16x32 form at twice the K
-BOUNDS = {"int8": (16, "i8", PEAK_I8_TOPS), "fp16": (8, "f16", PEAK_F16_TFLOPS)}  # sim_variant, dtype, peak
+BOUNDS = {"int8": (1, "i8", PEAK_I8_TOPS), "fp16": (0, "f16", PEAK_F16_TFLOPS)}  # sim_variant, dtype, peak
 PEAK_F64_VEC_TFLOPS = 78.6  # fp64 vector peak
 RANSAC_BYTES_PER_PAIR = 1_082_368  # 20 000 corr * 32 B + 4096 hyp * (96 + 12) B
 RANSAC_FLOPS_PER_EVAL = 92

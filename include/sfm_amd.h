@@ -62,9 +62,9 @@ const char *sfm_version(void);
 /* Tunables (all optional).  key: "cand_capacity" (candidate slots per image
  * pair, default 524288; pairs that need more are scored cell by cell),
  * "pairs_per_launch" (default 2048), "hyps_per_launch", "sim_variant"
- * (instance of the similarity kernel: 16 = int8 bound, the default; 8 = fp16
- * bound; the instances documented as ablations in match.hip give wrong
- * results and exist for timing only), "ransac_filter" (1 = skip evaluations the
+ * (instance of the similarity kernel: 1 = int8 bound, the default; 0 = fp16
+ * bound; 2..5 = ablations that give wrong results and exist for timing only),
+ * "ransac_filter" (1 = skip evaluations the
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
  * everything; results are identical).  Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */

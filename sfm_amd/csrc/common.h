@@ -19,7 +19,7 @@ struct sfm_ctx {
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
     int64_t hyps_per_launch = 0;     // 0 = all hypotheses of a RANSAC call in one launch
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
-    int sim_variant = 16;            // index into the similarity kernel's instance table
+    int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };
     std::vector<Span> span_pool[2]; // events are created once and reused

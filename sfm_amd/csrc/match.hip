@@ -32,7 +32,6 @@
 #pragma clang fp contract(off)
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float16v __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 typedef int int4v __attribute__((ext_vector_type(4)));
 
@@ -264,19 +263,25 @@ __device__ __forceinline__ int opaque_zero()
 // ---------------------------------------------------------------------------------------
 // similarity kernel
 // ---------------------------------------------------------------------------------------
-// Block = WAVES waves.  Wave w keeps RT*32 rows of image A as MFMA A-operand fragments in
-// registers for the whole block; image B streams through LDS, BN_ descriptors per step,
-// double buffered, one barrier per step.  LDS rows are 256 B (128 fp16); 16-byte chunk c of
-// row r is stored at chunk c ^ (r & 15), which makes the ds_read_b128 fragment reads
-// (32 rows, same logical chunk) conflict-free.
+// Block = SIM_WAVES waves and owns SIM_BLOCK_ROWS rows of image A: wave w keeps 64 rows x 128 k as
+// MFMA A-operand fragments in registers for the whole block; image B streams through LDS,
+// SIM_BN descriptors per step, double buffered, one barrier per step.
 //
-// MFMA operand map (32x32x16, f16): lane l, r = l & 31, h = l >> 5 holds A[row r][k = 8h..8h+7]
-// and B[k = 8h..8h+7][col r]; result register q of lane l is C[(q&3) + 8*(q>>2) + 4*h][r].
+// Two arithmetic forms of the bound:
+//   fp16 (v_mfma_f32_16x16x32_f16) on the unit-normalised fp16 table, rows of 256 B;
+//   int8 (v_mfma_i32_16x16x64_i8) on the quantised table, rows of 128 B, exact int32 sums.
+// Operand map of both: lane l holds A[row l & 15][k-group l >> 4] and B[k-group l >> 4][col l & 15]
+// (8 halves or 16 bytes per group); result register q of lane l is C[4 (l >> 4) + q][l & 15].
+#define SIM_WAVES 4
+#define SIM_WAVE_ROWS 64
+#define SIM_BLOCK_ROWS (SIM_WAVES * SIM_WAVE_ROWS)
+#define SIM_BN 64
 
 // Candidates leave the kernel through per-wave queues in global memory: every wave of every
 // block owns a fixed slice of its pair's candidate list and appends with plain stores at a
 // wave-uniform cursor, so the hot kernel has no atomics with return values and never waits on
-// memory in the candidate path.  A slice that fills up flags the pair for cell-by-cell scoring.
+// memory in the candidate path.  A slice that fills up flags the pair for the next, more
+// selective pass.
 struct WaveQueue {
     uint2 *base;
     int cap;
@@ -292,71 +297,35 @@ __device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int 
     wq.n += __builtin_popcountll(em);
 }
 
-// Accumulators of one 32-column step of a wave (RT*32 rows), for the two MFMA shapes.
-// A lane's values are numbered idx = 0..NV-1 in NGROUP groups that share a column.
-//   32x32x16: lane l holds column l & 31; register q of row tile t is row 32t + (q&3) + 8(q>>2) + 4(l>>5).
-//   16x16x32: lane l holds columns (l & 15) and 16 + (l & 15); register q of row tile t is row
-//             16t + 4(l>>4) + q.
+// Accumulators of one 32-column step of a wave (64 rows): 2 column tiles x 4 row tiles of 16x16.
+// A lane's 32 values are numbered idx = 16 ct + 4 t + q: column 16 ct + (l & 15), row
+// 16 t + 4 (l >> 4) + q.  The two groups of 16 (ct = 0, 1) share a column each.
 typedef float float4v __attribute__((ext_vector_type(4)));
-
-template <int RT> struct Acc32 {
-    typedef float VT;
-    static constexpr int NV = RT * 16, NGROUP = 1, GROUP = NV;
-    float16v a[RT];
-    __device__ __forceinline__ void zero()
-    {
-#pragma unroll
-        for (int t = 0; t < RT; t++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) a[t][q] = 0.0f;
-    }
-    __device__ __forceinline__ float get(int idx) const { return a[idx >> 4][idx & 15]; }
-    __device__ static __forceinline__ int row(int idx, int lane)
-    {
-        const int q = idx & 15;
-        return (idx >> 4) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-    }
-    __device__ static __forceinline__ int col(int, int lane) { return lane & 31; }
-};
-
-template <int RT> struct Acc16 {
-    typedef float VT;
-    static constexpr int RT16 = RT * 2, NV = 2 * RT16 * 4, NGROUP = 2, GROUP = RT16 * 4;
-    float4v a[2][RT16];
+template <typename V4, typename S> struct SimAcc {
+    typedef S VT;
+    static constexpr int NV = 32, NGROUP = 2, GROUP = 16;
+    V4 a[2][4];
     __device__ __forceinline__ void zero()
     {
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
-            for (int t = 0; t < RT16; t++)
+            for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) a[c][t][q] = 0.0f;
+                for (int q = 0; q < 4; q++) a[c][t][q] = S(0);
     }
-    __device__ __forceinline__ float get(int idx) const { return a[idx / GROUP][(idx % GROUP) >> 2][idx & 3]; }
-    __device__ static __forceinline__ int row(int idx, int lane)
+    __device__ __forceinline__ S get(int idx) const { return a[idx >> 4][(idx & 15) >> 2][idx & 3]; }
+    __device__ static __forceinline__ int row(int idx, int lane) { return ((idx & 15) >> 2) * 16 + 4 * (lane >> 4) + (idx & 3); }
+    __device__ static __forceinline__ int col(int idx, int lane) { return (idx >> 4) * 16 + (lane & 15); }
+    __device__ __forceinline__ void keep_alive() const // for the ablation without a candidate test
     {
-        return ((idx % GROUP) >> 2) * 16 + 4 * (lane >> 4) + (idx & 3);
-    }
-    __device__ static __forceinline__ int col(int idx, int lane) { return (idx / GROUP) * 16 + (lane & 15); }
-};
-
-// 16x16x64 int8 MFMA: the same value-to-cell map as Acc16, int32 values.
-template <int RT> struct Acc16i {
-    typedef int VT;
-    static constexpr int RT16 = RT * 2, NV = 2 * RT16 * 4, NGROUP = 2, GROUP = RT16 * 4;
-    int4v a[2][RT16];
-    __device__ __forceinline__ void zero()
-    {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
-            for (int t = 0; t < RT16; t++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) a[c][t][q] = 0;
+            for (int t = 0; t < 4; t++) asm volatile("" ::"v"(a[c][t]));
+#endif
     }
-    __device__ __forceinline__ int get(int idx) const { return a[idx / GROUP][(idx % GROUP) >> 2][idx & 3]; }
-    __device__ static __forceinline__ int row(int idx, int lane) { return Acc16<RT>::row(idx, lane); }
-    __device__ static __forceinline__ int col(int idx, int lane) { return Acc16<RT>::col(idx, lane); }
 };
 
 // What the general instance keeps in LDS besides the staged descriptors: the pixel positions of
@@ -371,39 +340,40 @@ struct GeneralLds {
 // the step.
 //
 // Strict instances (GENERAL = false) queue every cell above the bound; a slice that overflows
-// flags the pair, and the general instance then redoes the flagged pairs (loose thresholds,
-// where most cells clear the bound; always for the dot metric).
+// flags the pair, and a more selective pass then redoes the flagged pairs (int8 bound -> fp16
+// bound -> general instance; the dot metric always takes the general instance).
 //
-// The general instance runs twice per pair, once with each image in the register-resident role.
-// A wave streams all columns past its rows in order, so "can this cell still be the best of its
-// row" is a running-maximum test that needs no communication outside the wave: a cell inside the
-// pixel gate is queued only if its upper bound reaches the largest lower bound seen so far in its
-// row.  The true arg-max of the row always passes: its upper bound is at least its exact value,
-// which is at least every other cell's exact value, which is at least that cell's lower bound;
-// cells outside the gate (match.cpp:45) never raise a bound.  Pass 0 thus queues every row best
-// and pass 1 every column best.  The bounds live in LDS and are raised with an atomic max whose
-// returned previous value decides the test, so the lanes that hold one row in the same step see
-// each other in some serial order.  localLo[idx] is a per-lane copy of the row's bound minus the
-// margin, in registers, so that most cells are rejected by a register compare; it only ever
-// trails the shared bound, which keeps the test permissive.
+// The general instance (loose thresholds, where most cells clear the bound) runs twice per pair,
+// once with each image in the register-resident role.  A wave streams all columns past its rows
+// in order, so "can this cell still be the best of its row" is a running-maximum test that needs
+// no communication outside the wave: a cell inside the pixel gate is queued only if its upper
+// bound reaches the largest lower bound seen so far in its row.  The true arg-max of the row
+// always passes: its upper bound is at least its exact value, which is at least every other
+// cell's exact value, which is at least that cell's lower bound; cells outside the gate
+// (match.cpp:45) never raise a bound.  Pass 0 thus queues every row best and pass 1 every column
+// best.  The bounds live in LDS and are raised with an atomic max whose returned previous value
+// decides the test, so the lanes that hold one row in the same step see each other in some
+// serial order.  localLo[idx] is a per-lane copy of the row's bound minus the margin, in
+// registers, so that most cells are rejected by a register compare; it only ever trails the
+// shared bound, which keeps the test permissive.
 template <typename AccT, bool DOT, bool GENERAL>
 __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
                                              int colBase, int lane, typename AccT::VT thr_m, WaveQueue &wq,
                                              float (&localLo)[GENERAL ? AccT::NV : 1], const GeneralLds &gl)
 {
     constexpr int NV = AccT::NV;
-    static_assert(NV <= 32, "one bit per accumulator value");
-    unsigned bits = 0;
     constexpr bool INTEGER = std::is_same<typename AccT::VT, int>::value;
     static_assert(!INTEGER || !GENERAL, "the int8 bound has a strict instance only");
+    unsigned bits = 0;
     if constexpr (INTEGER) {
+        // Four independent chains keep the dependent-issue latency short; no branch, so the chain
+        // can be scheduled among MFMAs.
         int m[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
 #pragma unroll
         for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = max(max(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
         bits = max(max(m[0], m[1]), max(m[2], m[3])) > thr_m;
     } else if constexpr (!GENERAL) {
-        // fmaxf ignores NaNs, and a NaN cell can never be accepted.  Four independent chains keep
-        // the dependent-issue latency short; no branch, so the chain can be scheduled among MFMAs.
+        // the same in fp32; fmaxf ignores NaNs, and a NaN cell can never be accepted
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
         for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = fmaxf(fmaxf(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
@@ -440,7 +410,7 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         unsigned takeBits = 0;
 #pragma unroll
         for (int grp = 0; grp < AccT::NGROUP; grp++) {
-            constexpr unsigned groupMask = AccT::GROUP >= 32 ? 0xFFFFFFFFu : ((1u << AccT::GROUP) - 1u);
+            constexpr unsigned groupMask = (1u << AccT::GROUP) - 1u;
             const int cj = AccT::col(grp * AccT::GROUP, ln);
             const int jj = colBase + cj;
             const bool colValid = jj < pr.nB;
@@ -500,68 +470,39 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
     }
 }
 
-template <int RT> __device__ __forceinline__ void keep_alive(const Acc32<RT> &acc)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int t = 0; t < RT; t++) asm volatile("" ::"v"(acc.a[t]));
-#endif
-}
-template <int RT> __device__ __forceinline__ void keep_alive(const Acc16<RT> &acc)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int t = 0; t < 2 * RT; t++) asm volatile("" ::"v"(acc.a[c][t]));
-#endif
-}
-
-template <int RT> __device__ __forceinline__ void keep_alive(const Acc16i<RT> &acc)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int t = 0; t < 2 * RT; t++) asm volatile("" ::"v"(acc.a[c][t]));
-#endif
-}
-
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 // Image B reaches LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, written
-// linearly at a wave-uniform base), so the XOR swizzle is applied to the per-lane source address.
-// PIPE = 1: two accumulator sets; the candidate test of one 32-column step is issued among the
-// MFMAs of the next one.
-// ABL: timing-only ablations (wrong results): 1 = no staging and no barrier, 2 = no candidate test.
-template <int RT, int WAVES, int BN_, int OCC, int PIPE, bool DOT, int ABL, int STAGES, int MF16, bool GENERAL>
-__global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
+// linearly at a wave-uniform base), so the XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free is applied to the per-lane source address:
+//   fp16: 16-B chunk c of row r sits at chunk c ^ (r & 15) of its 256-B LDS line;
+//   int8: a 256-B LDS line holds rows 2L and 2L + 1; chunk c of row 2L + b sits at (8b + c) ^ (L & 15).
+// OCC = blocks per CU the register budget is set for.  I8 selects the int8 form (strict cosine only).
+// ABL: timing-only ablations with wrong results: bit 0 = no staging and no barrier, bit 1 = no
+// candidate test.
+template <int OCC, bool I8, bool DOT, bool GENERAL, int ABL>
+__global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
 {
-    constexpr int NSUB = BN_ / 32;
-    constexpr bool I8 = MF16 == 3;        // int8 table, 16x16x64 MFMA, integer bound
-    constexpr int ROWB = I8 ? 128 : 256;  // bytes per descriptor row in the table and in LDS
-    constexpr int DMA = BN_ * ROWB / 1024 / WAVES; // LDS-DMA instructions per wave per step
-    static_assert(BN_ * ROWB % (1024 * WAVES) == 0 && NSUB % 2 == 0, "step must split evenly");
-    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS buffers");
+    constexpr int ROWB = I8 ? 128 : 256;                   // bytes per descriptor row in the table and in LDS
+    constexpr int DMA = SIM_BN * ROWB / 1024 / SIM_WAVES;  // LDS-DMA instructions per wave per step
+    static_assert(SIM_BN * ROWB % (1024 * SIM_WAVES) == 0 && SIM_BN == 64, "step must split evenly");
     static_assert(!I8 || (!GENERAL && !DOT), "the int8 bound has a strict cosine instance only");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES][BN_ * ROWB];
-    // general instance: positions of the block's rows, of the staged columns, and the row bounds
-    constexpr int BLOCK_ROWS = WAVES * RT * 32;
-    __shared__ double2 ptsRow[GENERAL ? BLOCK_ROWS : 1];
-    __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? BN_ : 1];
-    __shared__ unsigned rowBound[GENERAL ? BLOCK_ROWS : 1];
-    static_assert(!GENERAL || (STAGES == 2 && PIPE == 0), "the general instance is double buffered, not pipelined");
-
     static_assert(GENERAL || !DOT, "the dot metric needs the general instance");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][SIM_BN * ROWB];
+    // general instance: positions of the block's rows, of the staged columns, and the row bounds
+    __shared__ double2 ptsRow[GENERAL ? SIM_BLOCK_ROWS : 1];
+    __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? SIM_BN : 1];
+    __shared__ unsigned rowBound[GENERAL ? SIM_BLOCK_ROWS : 1];
+
     const int2 w = g.work[blockIdx.x];
     if (w.x < 0) return;
     if (g.onlyFlagged && g.pairOvf[w.x] != g.onlyFlagged) return; // later passes: pairs an earlier pass gave up on
     PairRec pr = g.pairs[w.x];
-    // slices of the pair's candidate list: one per wave of the strict pass, or one per wave of
+    // slices of the pair's candidate list: one per wave of a strict pass, or one per wave of
     // both orientations of the general pass
-    const int nQ0 = ((pr.nA + WAVES * RT * 32 - 1) / (WAVES * RT * 32)) * WAVES;
-    const int nQ1 = ((pr.nB + WAVES * RT * 32 - 1) / (WAVES * RT * 32)) * WAVES;
+    const int nQ0 = ((pr.nA + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
+    const int nQ1 = ((pr.nB + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
     if (GENERAL && g.orient) { // image B's rows stay in registers, image A streams
         const int n = pr.nA; pr.nA = pr.nB; pr.nB = n;
         int64_t t = pr.rowA32; pr.rowA32 = pr.rowB32; pr.rowB32 = t;
@@ -570,137 +511,80 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int rowBase = w.y * (WAVES * RT * 32) + wave * (RT * 32);
+    const int rowBase = w.y * SIM_BLOCK_ROWS + wave * SIM_WAVE_ROWS;
 
-    const _Float16 *A16 = g.desc16 + (size_t)(pr.rowA16 + rowBase) * KDIM;
-    const unsigned char *B16 = I8 ? reinterpret_cast<const unsigned char *>(g.desc8) + (size_t)pr.rowB16 * 128
-                                  : reinterpret_cast<const unsigned char *>(g.desc16 + (size_t)pr.rowB16 * KDIM);
+    const unsigned char *table = I8 ? reinterpret_cast<const unsigned char *>(g.desc8) : reinterpret_cast<const unsigned char *>(g.desc16);
+    const unsigned char *Arows = table + (size_t)(pr.rowA16 + rowBase) * ROWB;
+    const unsigned char *Brows = table + (size_t)pr.rowB16 * ROWB;
 
-    // A fragments.  32x32x16: a[t][s] = rows 32t + (l & 31), k = 16s + 8(l >> 5) .. +7.
-    //               16x16x32: a[t][s] = rows 16t + (l & 15), k = 32s + 8(l >> 4) .. +7.
-    //               16x16x64 (int8): a8[t][s] = rows 16t + (l & 15), k = 64s + 16(l >> 4) .. +15.
-    constexpr int NA_T = MF16 ? 2 * RT : RT, NA_S = I8 ? 1 : (MF16 ? 4 : 8);
-    half8 a[NA_T][NA_S];
-    int4v a8[I8 ? 2 * RT : 1][2];
-    if constexpr (I8) {
-        const unsigned char *A8 = reinterpret_cast<const unsigned char *>(g.desc8) + (size_t)(pr.rowA16 + rowBase) * 128;
+    // A fragments: row tile t (16 rows), k-block s; fp16 has four k-blocks of 32, int8 two of 64.
+    constexpr int NKB = I8 ? 2 : 4;
+    typedef typename std::conditional<I8, int4v, half8>::type Frag; // 16 bytes either way
+    Frag a[4][NKB];
 #pragma unroll
-        for (int t = 0; t < 2 * RT; t++)
+    for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int s = 0; s < 2; s++)
-                a8[t][s] = *reinterpret_cast<const int4v *>(A8 + (size_t)(t * 16 + (lane & 15)) * 128 + s * 64 + (lane >> 4) * 16);
-    } else {
-#pragma unroll
-        for (int t = 0; t < NA_T; t++)
-#pragma unroll
-            for (int s = 0; s < NA_S; s++)
-                a[t][s] = MF16 ? *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 16 + (lane & 15)) * KDIM + s * 32 + (lane >> 4) * 8)
-                               : *reinterpret_cast<const half8 *>(A16 + (size_t)(t * 32 + r) * KDIM + s * 16 + h * 8);
-    }
+        for (int s = 0; s < NKB; s++)
+            a[t][s] = *reinterpret_cast<const Frag *>(Arows + (size_t)(t * 16 + (lane & 15)) * ROWB + (s * 4 + (lane >> 4)) * 16);
 
-    const int nChunks = (pr.nB + BN_ - 1) / BN_;
+    const int nChunks = (pr.nB + SIM_BN - 1) / SIM_BN;
     // the bound is the same for the whole block: keep it (and the branch on it) scalar
     const float thr_m = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m)));
     const int thr_i = __builtin_amdgcn_readfirstlane(pr.thr_i);
 
-    // LDS-DMA: instruction u of this wave fills 1 KiB = rows 4*blk .. 4*blk+3 of the step; lane l
-    // lands at row 4*blk + (l >> 4), physical chunk l & 15, which holds logical chunk (l & 15) ^ (row & 15).
-    // int8 rows are 128 B, so a 256-B LDS line holds rows 2L and 2L + 1: 16-B chunk c of row 2L + b
-    // sits at position (8b + c) ^ (L & 15) of line L.
+    // LDS-DMA: instruction u of this wave fills 1 KiB = four 256-B lines of the step; lane l lands
+    // on line 4 (wave DMA + u) + (l >> 4), physical position l & 15, which holds the logical
+    // position (l & 15) ^ (line & 15).
     unsigned srcOff[DMA];
 #pragma unroll
     for (int u = 0; u < DMA; u++) {
-        const int row = 4 * (wave * DMA + u) + (lane >> 4); // 256-B line of the step
-        const int logical = (lane & 15) ^ (row & 15);
-        srcOff[u] = I8 ? (2 * row + (logical >> 3)) * 128 + ((logical & 7) << 4) : row * 256 + (logical << 4);
+        const int line = 4 * (wave * DMA + u) + (lane >> 4);
+        const int logical = (lane & 15) ^ (line & 15);
+        srcOff[u] = I8 ? (2 * line + (logical >> 3)) * 128 + ((logical & 7) << 4) : line * 256 + (logical << 4);
     }
     auto dma_issue = [&](int c, int buf) {
-        const unsigned char *src = B16 + (size_t)c * BN_ * ROWB;
+        const unsigned char *src = Brows + (size_t)c * SIM_BN * ROWB;
 #pragma unroll
         for (int u = 0; u < DMA; u++)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + srcOff[u]), (lptr_t)&lds[buf][(wave * DMA + u) * 1024], 16, 0, 0);
-        if constexpr (GENERAL) { // the step's pixel positions, 64 columns per instruction (the table has no padding)
+        if constexpr (GENERAL) { // the step's 64 pixel positions: one instruction (the table has no padding)
             if (wave == 0) {
-#pragma unroll
-                for (int u = 0; u < BN_ / 64; u++) {
-                    const int j = min(c * BN_ + u * 64 + lane, pr.nB - 1);
-                    __builtin_amdgcn_global_load_lds((gptr_t)(g.pts + pr.rowB32 + j), (lptr_t)&ptsCol[buf & 1][u * 64], 16, 0, 0);
-                }
+                const int j = min(c * SIM_BN + lane, pr.nB - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(g.pts + pr.rowB32 + j), (lptr_t)&ptsCol[buf][0], 16, 0, 0);
             }
         }
     };
     if constexpr (GENERAL) {
-        for (int rr = tid; rr < BLOCK_ROWS; rr += WAVES * 64) {
-            ptsRow[rr] = g.pts[pr.rowA32 + min(w.y * BLOCK_ROWS + rr, pr.nA - 1)];
+        for (int rr = tid; rr < SIM_BLOCK_ROWS; rr += SIM_WAVES * 64) {
+            ptsRow[rr] = g.pts[pr.rowA32 + min(w.y * SIM_BLOCK_ROWS + rr, pr.nA - 1)];
             rowBound[rr] = 0;
         }
     }
-    using AccT = typename std::conditional<I8, Acc16i<RT>, typename std::conditional<MF16 != 0, Acc16<RT>, Acc32<RT>>::type>::type;
+    using AccT = typename std::conditional<I8, SimAcc<int4v, int>, SimAcc<float4v, float>>::type;
+    // one 32-column step: column tile ct, k-block s: one B fragment from LDS feeds four MFMAs
     auto mfma_step = [&](AccT &acc, int buf, int sub) {
         acc.zero();
-        if constexpr (I8) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ct++)
+        for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    const int row = sub * 32 + ct * 16 + (lane & 15);
-                    const int line = row >> 1;
-                    const int pos = ((row & 1) * 8 + 4 * s + (lane >> 4)) ^ (line & 15);
-                    const int4v b = *reinterpret_cast<const int4v *>(&lds[buf][line * 256 + (pos << 4)]);
+            for (int s = 0; s < NKB; s++) {
+                const int row = sub * 32 + ct * 16 + (lane & 15);
+                const int chunk = s * 4 + (lane >> 4);
+                const int at = I8 ? (row >> 1) * 256 + ((((row & 1) * 8 + chunk) ^ ((row >> 1) & 15)) << 4)
+                                  : row * 256 + ((chunk ^ (row & 15)) << 4);
+                const Frag b = *reinterpret_cast<const Frag *>(&lds[buf][at]);
 #pragma unroll
-                    for (int t = 0; t < 2 * RT; t++)
-                        acc.a[ct][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[t][s], b, acc.a[ct][t], 0, 0, 0);
-                }
-        } else if constexpr (MF16 == 2) {
-            // B fragments one ahead of their use: the LDS read of fragment k + 1 is issued before the
-            // MFMAs of fragment k, so its latency hides behind them
-            auto ldb = [&](int idx) {
-                const int row = sub * 32 + (idx >> 2) * 16 + (lane & 15);
-                return *reinterpret_cast<const half8 *>(&lds[buf][row * 256 + (((4 * (idx & 3) + (lane >> 4)) ^ (row & 15)) << 4)]);
-            };
-            half8 bc = ldb(0);
-#pragma unroll
-            for (int idx = 0; idx < 8; idx++) {
-                half8 bn = bc;
-                if (idx < 7) bn = ldb(idx + 1);
-#pragma unroll
-                for (int t = 0; t < 2 * RT; t++)
-                    acc.a[idx >> 2][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][idx & 3], bc, acc.a[idx >> 2][t], 0, 0, 0);
-                bc = bn;
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-            for (int idx = 0; idx < 7; idx++) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT, 0);
-#endif
-        } else if constexpr (MF16 != 0) {
-#pragma unroll
-            for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int row = sub * 32 + ct * 16 + (lane & 15);
-                    const half8 b = *reinterpret_cast<const half8 *>(&lds[buf][row * 256 + (((4 * s + (lane >> 4)) ^ (row & 15)) << 4)]);
-#pragma unroll
-                    for (int t = 0; t < 2 * RT; t++)
+                for (int t = 0; t < 4; t++) {
+                    if constexpr (I8)
+                        acc.a[ct][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][s], b, acc.a[ct][t], 0, 0, 0);
+                    else
                         acc.a[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][s], b, acc.a[ct][t], 0, 0, 0);
                 }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const half8 b = *reinterpret_cast<const half8 *>(&lds[buf][(sub * 32 + r) * 256 + (((2 * s + h) ^ (r & 15)) << 4)]);
-#pragma unroll
-                for (int t = 0; t < RT; t++) acc.a[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][s], b, acc.a[t], 0, 0, 0);
             }
-        }
     };
     // this wave's slice of the pair's candidate list
     const int nQueues = GENERAL ? nQ0 + nQ1 : nQ0;
-    const int queueId = ((GENERAL && g.orient) ? nQ0 : 0) + w.y * WAVES + wave;
+    const int queueId = ((GENERAL && g.orient) ? nQ0 : 0) + w.y * SIM_WAVES + wave;
     float localLo[GENERAL ? AccT::NV : 1];
 #pragma unroll
     for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
@@ -711,40 +595,20 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
     int buf = 0;
     auto test = [&](const AccT &acc, int colBase) {
         if constexpr ((ABL & 2) != 0)
-            keep_alive<RT>(acc);
+            acc.keep_alive();
         else
             sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, typename AccT::VT(I8 ? thr_i : thr_m), wq, localLo,
-                                             GeneralLds{ptsRow + (GENERAL ? wave * RT * 32 : 0),
-                                                        &ptsCol[GENERAL ? buf & 1 : 0][GENERAL ? (colBase % BN_) : 0],
-                                                        rowBound + (GENERAL ? wave * RT * 32 : 0)});
+                                             GeneralLds{ptsRow + (GENERAL ? wave * SIM_WAVE_ROWS : 0),
+                                                        &ptsCol[GENERAL ? buf : 0][GENERAL ? (colBase % SIM_BN) : 0],
+                                                        rowBound + (GENERAL ? wave * SIM_WAVE_ROWS : 0)});
     };
 
-    AccT accA, accB;
-    int jPrev = 0x40000000; // "no previous step": beyond every column
-    if (PIPE) accB.zero();
-    // STAGES == 2: step c+1 is in flight while step c is consumed; one barrier per step, after it.
-    // STAGES == 3: steps c+1 and c+2 are in flight.  The barrier at the top of iteration c says:
-    // every wave's share of step c has landed (each wave waits until at most its newest DMA group,
-    // step c+1, is outstanding) and every wave is done reading the buffer of step c-1, which is
-    // the one step c+2 overwrites.
+    AccT acc;
+    // step c + 1 is in flight while step c is consumed; one barrier per step, after it
     dma_issue(0, 0);
-    if (STAGES == 2)
-        __syncthreads();
-    else if (nChunks > 1)
-        dma_issue(1, 1);
+    __syncthreads();
     for (int c = 0; c < nChunks; c++) {
-        if (STAGES == 2) {
-            if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
-        } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (c + 1 < nChunks)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            __builtin_amdgcn_s_barrier();
-            if (c + 2 < nChunks) dma_issue(c + 2, (buf == 0) ? 2 : buf - 1);
-        }
+        if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
         if constexpr (GENERAL && !DOT) {
             // Pull the shared row bounds into the per-lane copies: a lane learns of a bound raised by
             // another lane's column only here or when one of its own cells gets past its stale copy.
@@ -752,39 +616,23 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
             if (c < 8 || (c & 7) == 0) {
 #pragma unroll
                 for (int idx = 0; idx < AccT::NV; idx++) {
-                    const unsigned key = rowBound[wave * RT * 32 + AccT::row(idx, lane)];
+                    const unsigned key = rowBound[wave * SIM_WAVE_ROWS + AccT::row(idx, lane)];
                     localLo[idx] = fmaxf(localLo[idx], (key ? ordered_value(key) : -INFINITY) - SIM_MARGIN);
                 }
             }
         }
         // a strict wave whose slice has overflowed only keeps the staging going: the pair is redone anyway
-        if (GENERAL || PIPE || wq.n <= wq.cap)
-#pragma unroll
-        for (int sub = 0; sub < NSUB; sub += 2) {
-            const int j0 = c * BN_ + sub * 32;
-            if (PIPE) {
-                mfma_step(accA, buf, sub);
-                test(accB, jPrev);
-                mfma_step(accB, buf, sub + 1);
-                test(accA, j0);
-                jPrev = j0 + 32;
-            } else {
-                mfma_step(accA, buf, sub);
-                test(accA, j0);
-                mfma_step(accA, buf, sub + 1);
-                test(accA, j0 + 32);
-            }
+        if (GENERAL || wq.n <= wq.cap) {
+            mfma_step(acc, buf, 0);
+            test(acc, c * SIM_BN);
+            mfma_step(acc, buf, 1);
+            test(acc, c * SIM_BN + 32);
         }
-        if (STAGES == 2) {
-            if (!(ABL & 1)) {
-                __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
-                buf ^= 1;
-            }
-        } else {
-            buf = (buf == 2) ? 0 : buf + 1;
+        if (!(ABL & 1)) {
+            __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
+            buf ^= 1;
         }
     }
-    if (PIPE) test(accB, jPrev);
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
         if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = GENERAL ? 2 : (I8 ? 3 : 1);
@@ -793,50 +641,21 @@ __global__ __launch_bounds__(WAVES * 64, OCC) void match_sim_kernel(const MatchA
 
 // The instances that can be selected with sfm_ctx_set_option("sim_variant").
 struct SimVariant {
-    int blockRows, threads;
-    void (*strict)(const MatchArgs);  // cosine, every cell above the bound is queued
-    void (*strict16)(const MatchArgs); // i8 instances: the fp16 strict instance that redoes pairs the int8 bound flooded
-    void (*general)(const MatchArgs); // cosine with the row/column-best filter
-    void (*dot)(const MatchArgs);
+    void (*strict)(const MatchArgs);   // cosine, every cell above the bound is queued
+    void (*strict16)(const MatchArgs); // int8 bound only: the fp16 strict instance that redoes pairs the int8 bound flooded
     const char *name;
-    bool i8 = false; // the strict instance bounds with the int8 table
 };
-#define SIM_VARIANT(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES, MF16)                                              \
-    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, MF16, false>, \
-     nullptr,                                                                                                   \
-     match_sim_kernel<RT, WAVES, BN_, 2, 0, false, ABL, 2, MF16, true>,                                         \
-     match_sim_kernel<RT, WAVES, BN_, 2, 0, true, ABL, 2, MF16, true>,                                          \
-     "rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_pipe" #PIPE "_abl" #ABL "_st" #STAGES "_mf16" #MF16}
-// int8 bound for the strict pass; the general and dot instances are the fp16 ones of the same geometry
-#define SIM_VARIANT_I8(RT, WAVES, BN_, OCC, ABL, STAGES) SIM_VARIANT_I8P(RT, WAVES, BN_, OCC, 0, ABL, STAGES)
-#define SIM_VARIANT_I8P(RT, WAVES, BN_, OCC, PIPE, ABL, STAGES)                                               \
-    {WAVES * RT * 32, WAVES * 64, match_sim_kernel<RT, WAVES, BN_, OCC, PIPE, false, ABL, STAGES, 3, false>,   \
-     match_sim_kernel<RT, WAVES, 64, 4, 0, false, 0, 2, 1, false>,                                            \
-     match_sim_kernel<RT, WAVES, 64, 2, 0, false, 0, 2, 1, true>,                                             \
-     match_sim_kernel<RT, WAVES, 64, 2, 0, true, 0, 2, 1, true>,                                              \
-     "i8_rt" #RT "_w" #WAVES "_bn" #BN_ "_occ" #OCC "_abl" #ABL "_st" #STAGES, true}
 static const SimVariant kSimVariants[] = {
-    SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 0), // 0: 8 waves x 64 rows, one block per CU
-    SIM_VARIANT(2, 8, 128, 2, 1, 0, 2, 0), // 1: pipelined candidate test
-    SIM_VARIANT(2, 8, 128, 2, 0, 0, 2, 1), // 2: 16x16x32 MFMA
-    SIM_VARIANT(2, 8, 128, 2, 1, 0, 2, 1), // 3
-    SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 0),  // 4: 4 waves x 64 rows, three blocks per CU
-    SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 1),  // 5: same with 16x16x32 MFMA
-    SIM_VARIANT(2, 4, 64, 2, 1, 0, 2, 1),  // 6
-    SIM_VARIANT(2, 4, 64, 3, 0, 0, 3, 1),  // 7
-    SIM_VARIANT(2, 4, 64, 4, 0, 0, 2, 1),  // 8: four blocks per CU (<= 128 VGPRs)
-    SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 0),  // 9: ablation of 4, no candidate test
-    SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 0),  // 10: ablation of 4, neither staging nor test
-    SIM_VARIANT(2, 4, 64, 3, 0, 2, 2, 1),  // 11: ablation of 5, no candidate test
-    SIM_VARIANT(2, 4, 64, 3, 0, 3, 2, 1),  // 12: ablation of 5, neither
-    SIM_VARIANT(2, 4, 64, 4, 0, 0, 2, 2),  // 13: 8 with B fragments read one ahead
-    SIM_VARIANT(2, 4, 64, 3, 0, 0, 2, 2),  // 14: 5 with B fragments read one ahead
-    SIM_VARIANT_I8(2, 4, 64, 4, 0, 2),     // 15: int8 bound, 16x16x64 MFMA, same block geometry as 8
-    SIM_VARIANT_I8(2, 4, 64, 5, 0, 2),     // 16
-    SIM_VARIANT_I8(2, 4, 128, 4, 0, 2),    // 17: 128 descriptors per step
-    SIM_VARIANT_I8(2, 4, 64, 4, 2, 2),     // 18: ablation of 15, no candidate test
-    SIM_VARIANT_I8(2, 4, 64, 4, 3, 2),     // 19: ablation of 15, neither staging nor test
+    {match_sim_kernel<4, false, false, false, 0>, nullptr, "fp16 bound"},                                       // 0
+    {match_sim_kernel<5, true, false, false, 0>, match_sim_kernel<4, false, false, false, 0>, "int8 bound"},    // 1: default
+    {match_sim_kernel<4, false, false, false, 2>, nullptr, "fp16, no candidate test (timing only)"},            // 2
+    {match_sim_kernel<4, false, false, false, 3>, nullptr, "fp16, neither staging nor test (timing only)"},     // 3
+    {match_sim_kernel<5, true, false, false, 2>, nullptr, "int8, no candidate test (timing only)"},             // 4
+    {match_sim_kernel<5, true, false, false, 3>, nullptr, "int8, neither staging nor test (timing only)"},      // 5
 };
+// cosine with the row-best filter (loose thresholds), and the dot metric: fp16 bound, two blocks per CU
+static void (*const kSimGeneral)(const MatchArgs) = match_sim_kernel<2, false, false, true, 0>;
+static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
 // ---------------------------------------------------------------------------------------
@@ -1347,7 +1166,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     sfm_span_reset(ctx, 0);
 
     const SimVariant &variant = kSimVariants[ctx->sim_variant];
-    const int BLOCK_ROWS = variant.blockRows; // <= ROW_PAD
+    const int BLOCK_ROWS = SIM_BLOCK_ROWS; // <= ROW_PAD
     const int chunkPairs = (int)std::min<int64_t>(ctx->pairs_per_launch, n_pairs > 0 ? n_pairs : 1);
     const int candCap = (int)ctx->cand_capacity;
 
@@ -1363,7 +1182,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     std::vector<int> chunkWorkCount[2];
     int64_t workTotal = 0;
     int maxNA = 0, maxNB = 0;
-    const int wavesPerBlock = variant.threads / 64;
+    const int wavesPerBlock = SIM_WAVES;
     auto row_blocks = [&](int nA, int nB, int orient) {
         if (nA <= 0 || nB <= 0) return 0;
         return ((orient ? nB : nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
@@ -1523,12 +1342,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             if (cosine) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0));
                 g.onlyFlagged = 0;
-                hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(variant.threads), 0, st, g);
+                hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
                 SFM_HIP(ctx, sfm_span_end(ctx, 0));
             }
             if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 g.onlyFlagged = 3;
-                hipLaunchKernelGGL(variant.strict16, dim3(nblk), dim3(variant.threads), 0, st, g);
+                hipLaunchKernelGGL(variant.strict16, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
             }
             // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
             // orientations.  Dot: every pair takes this path.
@@ -1537,8 +1356,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 g.orient = o;
                 g.work = workList[o];
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0));
-                hipLaunchKernelGGL(cosine ? variant.general : variant.dot, dim3(chunkWorkCount[o][ci]),
-                                   dim3(variant.threads), 0, st, g);
+                hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(chunkWorkCount[o][ci]),
+                                   dim3(SIM_WAVES * 64), 0, st, g);
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0));
             }
             g.onlyFlagged = 0;

@@ -8,7 +8,7 @@ from sfm_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
-FP16_BOUND, INT8_BOUND = 8, 16
+FP16_BOUND, INT8_BOUND = 0, 1
 
 
 @pytest.fixture(params=[FP16_BOUND, INT8_BOUND], ids=["fp16", "int8"])
