@@ -542,7 +542,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
         const int logical = (lane & 15) ^ (line & 15);
         srcOff[u] = I8 ? (2 * line + (logical >> 3)) * 128 + ((logical & 7) << 4) : line * 256 + (logical << 4);
     }
-    auto dma_issue = [&](int c, int buf) {
+    auto dma_issue = [&](int c, int buf) __attribute__((always_inline)) {
         const unsigned char *src = Brows + (size_t)c * SIM_BN * ROWB;
 #pragma unroll
         for (int u = 0; u < DMA; u++)
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     }
     using AccT = typename std::conditional<I8, SimAcc<int4v, int>, SimAcc<float4v, float>>::type;
     // one 32-column step: column tile ct, k-block s: one B fragment from LDS feeds four MFMAs
-    auto mfma_step = [&](AccT &acc, int buf, int sub) {
+    auto mfma_step = [&](AccT &acc, int buf, int sub) __attribute__((always_inline)) {
         acc.zero();
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
@@ -592,8 +592,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     wq.cap = g.candCap / nQueues;
     wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
     wq.n = 0;
-    int buf = 0;
-    auto test = [&](const AccT &acc, int colBase) {
+    auto test = [&](const AccT &acc, int colBase, int buf) __attribute__((always_inline)) {
         if constexpr ((ABL & 2) != 0)
             acc.keep_alive();
         else
@@ -604,10 +603,10 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     };
 
     AccT acc;
-    // step c + 1 is in flight while step c is consumed; one barrier per step, after it
-    dma_issue(0, 0);
-    __syncthreads();
-    for (int c = 0; c < nChunks; c++) {
+    // Step c + 1 is in flight while step c is consumed; one barrier per step, after it.  The loop
+    // is unrolled over the two LDS buffers so that every LDS address is a per-lane base plus an
+    // immediate: no address arithmetic competes with the MFMAs for the vector issue port.
+    auto step = [&](int c, const int buf) __attribute__((always_inline)) {
         if (!(ABL & 1) && c + 1 < nChunks) dma_issue(c + 1, buf ^ 1);
         if constexpr (GENERAL && !DOT) {
             // Pull the shared row bounds into the per-lane copies: a lane learns of a bound raised by
@@ -624,14 +623,17 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
         // a strict wave whose slice has overflowed only keeps the staging going: the pair is redone anyway
         if (GENERAL || wq.n <= wq.cap) {
             mfma_step(acc, buf, 0);
-            test(acc, c * SIM_BN);
+            test(acc, c * SIM_BN, buf);
             mfma_step(acc, buf, 1);
-            test(acc, c * SIM_BN + 32);
+            test(acc, c * SIM_BN + 32, buf);
         }
-        if (!(ABL & 1)) {
-            __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
-            buf ^= 1;
-        }
+        if (!(ABL & 1)) __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
+    };
+    dma_issue(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nChunks; c += 2) {
+        step(c, 0);
+        if (c + 1 < nChunks) step(c + 1, (ABL & 1) ? 0 : 1);
     }
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
