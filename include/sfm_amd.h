@@ -61,7 +61,10 @@ const char *sfm_version(void);
 
 /* Tunables (all optional).  key: "cand_capacity" (candidate slots per image
  * pair, default 524288; pairs that need more are scored cell by cell),
- * "pairs_per_launch" (default 2048), "hyps_per_launch", "sim_variant"
+ * "pairs_per_launch" (default 2048), "hyps_per_launch" (rows of the first
+ * slice of an adaptive RANSAC batch: rows are scored in slices growing by a
+ * factor of four and pairs whose scan has stopped skip the later ones;
+ * default 0 = sized to fill the device), "sim_variant"
  * (instance of the similarity kernel: 1 = int8 bound, the default; 0 = fp16
  * bound; 2..5 = ablations that give wrong results and exist for timing only),
  * "ransac_filter" (1 = skip evaluations the

@@ -17,7 +17,7 @@ struct sfm_ctx {
     // tunables
     int64_t cand_capacity = 524288;  // candidate slots per image pair
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
-    int64_t hyps_per_launch = 0;     // 0 = all hypotheses of a RANSAC call in one launch
+    int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)

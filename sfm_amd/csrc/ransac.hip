@@ -53,6 +53,11 @@ struct RansacArgs {
     int H;
     int adaptive;
     int loss;
+    // Hypotheses are evaluated in phases [hBegin, hEnd): a pair whose in-order scan has already
+    // stopped (RANSAC.cpp:189, :245-258) takes no part in later phases.
+    int hBegin, hEnd;
+    int *active;  // [P] 1 while the pair's scan has not stopped
+    int *maxIter; // [P] the scan's current iteration cap
 };
 
 // ---------------------------------------------------------------------------------------
@@ -323,10 +328,10 @@ __device__ __forceinline__ void svd3(const double E[3][3], double U[3][3], doubl
 __global__ __launch_bounds__(64) void ransac_fit_kernel(const RansacArgs g)
 {
     const int p = blockIdx.y;
-    const int h = blockIdx.x * 64 + threadIdx.x;
+    const int h = g.hBegin + blockIdx.x * 64 + threadIdx.x;
     const int64_t base = g.corrOff[p];
     const int64_t n = g.corrOff[p + 1] - base;
-    if (h >= g.H || n < 8) return;
+    if (h >= g.hEnd || n < 8 || !g.active[p]) return;
     const int32_t *s = g.samples + ((size_t)p * g.H + h) * 8;
     int idx[8];
     bool valid = true;
@@ -452,10 +457,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
     __shared__ __attribute__((aligned(16))) float rec32[(SCORE_CH / 2) * 12];
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
-    const int h = blockIdx.x * 256 + tid;
+    const int h = g.hBegin + blockIdx.x * 256 + tid;
     const int64_t base = g.corrOff[p];
     const int n = (int)(g.corrOff[p + 1] - base);
-    const bool active = h < g.H;
+    if (!g.active[p]) return; // the pair's scan stopped in an earlier phase
+    const bool active = h < g.hEnd;
     Pose P;
     load_pose(g.pose12 + ((size_t)p * g.H + (active ? h : 0)) * 12, P);
     double E[3][3];
@@ -595,13 +601,22 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
             g.bestCount[p] = 0;
             g.bestErr[p] = INFINITY;
             g.iterations[p] = 0;
+            g.active[p] = 0;
         }
         return;
     }
-    for (int t0 = 0; t0 < g.H; t0 += SEL_TILE) {
+    if (!g.active[p]) return;
+    if (g.hBegin > 0) { // resume the scan where the previous phase left it
+        maxIter = g.maxIter[p];
+        iterationsDone = g.iterations[p];
+        bestCount = g.bestCount[p];
+        best = g.bestH[p];
+        bestError = g.bestErr[p];
+    }
+    for (int t0 = g.hBegin; t0 < g.hEnd; t0 += SEL_TILE) {
         __syncthreads();
         if (sDone) break;
-        const int m = min(SEL_TILE, g.H - t0);
+        const int m = min(SEL_TILE, g.hEnd - t0);
         for (int q = tid; q < m; q += 256) {
             sc[q] = g.counts[(size_t)p * g.H + t0 + q];
             se[q] = g.toterr[(size_t)p * g.H + t0 + q];
@@ -637,6 +652,9 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
         g.bestCount[p] = bestCount;
         g.bestErr[p] = bestError;
         g.iterations[p] = iterationsDone;
+        g.maxIter[p] = maxIter;
+        // the scan goes on iff it consumed this phase without reaching its cap and rows remain
+        g.active[p] = (iterationsDone < maxIter && g.hEnd < g.H) ? 1 : 0;
     }
 }
 
@@ -954,7 +972,7 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter;
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
 };
@@ -966,14 +984,15 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
-                      &b->refitPose, &b->refitUsed, &b->refitPoints};
+                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter};
     for (DevBuf *d : bufs) d->release();
     delete b;
 }
 
 static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
                       const double *K, const int32_t *samples, int n_hyp, double maxSqErr, double successProb,
-                      int adaptive, int loss, bool on_device, bool fit_only, sfm_ransac_batch **batch_inout)
+                      int adaptive, int loss, bool on_device, bool fit_only, sfm_ransac_batch **batch_inout,
+                      bool phased = true)
 {
     if (!ctx || !batch_inout) return SFM_ERR_INVALID_ARG;
     if (n_pairs < 0 || n_hyp < 0 || (n_pairs > 0 && !corr_offsets))
@@ -1083,25 +1102,48 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.adaptive = adaptive;
     g.loss = loss;
 
-    if (n_hyp > 0) {
-        // poses of rows that are never fitted (pairs with n < 8) must not be read as garbage
-        SFM_HIP(ctx, hipMemsetAsync(b->pose12.p, 0, (size_t)n_pairs * n_hyp * 12 * sizeof(double), st));
-        hipLaunchKernelGGL(ransac_fit_kernel, dim3((n_hyp + 63) / 64, n_pairs), dim3(64), 0, st, g);
+    // Phases of hypothesis rows.  With the adaptive cap on, a pair whose in-order scan has stopped
+    // needs no further rows, so rows are fitted and scored in growing slices and the scan is resumed
+    // after each; the first slice is sized to fill the device (a slice's grid is rows / 256 blocks
+    // per pair).  Without the cap, or when the caller wants every row's score, one phase covers all.
+    SFM_HIP(ctx, b->active.reserve(P1 * sizeof(int)));
+    SFM_HIP(ctx, b->maxIter.reserve(P1 * sizeof(int)));
+    g.active = b->active.as<int>();
+    g.maxIter = b->maxIter.as<int>();
+    SFM_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)b->active.p, 1, (size_t)n_pairs, st));
+    std::vector<int> bounds{0};
+    if (phased && adaptive && !fit_only) {
+        int64_t h = 256 * std::max<int64_t>(1, (2560 + n_pairs - 1) / n_pairs);
+        if (ctx->hyps_per_launch > 0) h = 256 * ((ctx->hyps_per_launch + 255) / 256); // caller's first slice
+        while (h < n_hyp) {
+            bounds.push_back((int)h);
+            h *= 4;
+        }
     }
-    if (!fit_only) {
-        if (total > 0)
-            hipLaunchKernelGGL(ransac_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, total);
-        if (n_hyp > 0) {
+    bounds.push_back(n_hyp);
+    if (n_hyp > 0) // poses of rows that are never fitted must not be read as garbage
+        SFM_HIP(ctx, hipMemsetAsync(b->pose12.p, 0, (size_t)n_pairs * n_hyp * 12 * sizeof(double), st));
+    if (!fit_only && total > 0)
+        hipLaunchKernelGGL(ransac_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, total);
+    for (size_t ph = 0; ph + 1 < bounds.size(); ph++) {
+        g.hBegin = bounds[ph];
+        g.hEnd = bounds[ph + 1];
+        const int rows = g.hEnd - g.hBegin;
+        if (rows > 0) hipLaunchKernelGGL(ransac_fit_kernel, dim3((rows + 63) / 64, n_pairs), dim3(64), 0, st, g);
+        if (fit_only) continue;
+        if (rows > 0) {
             SFM_HIP(ctx, sfm_span_begin(ctx, 1));
             if (loss == SFM_LOSS_SAMPSON)
-                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON>), dim3((n_hyp + 255) / 256, n_pairs),
-                                   dim3(256), 0, st, g);
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON>), dim3((rows + 255) / 256, n_pairs), dim3(256),
+                                   0, st, g);
             else
-                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION>), dim3((n_hyp + 255) / 256, n_pairs),
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION>), dim3((rows + 255) / 256, n_pairs),
                                    dim3(256), 0, st, g);
             SFM_HIP(ctx, sfm_span_end(ctx, 1));
         }
         hipLaunchKernelGGL(ransac_select_kernel, dim3(n_pairs), dim3(256), 0, st, g);
+    }
+    if (!fit_only) {
         hipLaunchKernelGGL((ransac_inlier_kernel<false>), dim3(n_pairs), dim3(256), 0, st, g);
         hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(1024), 0, st, g.inlCount, n_pairs, b->inlOff.as<int64_t>());
         hipLaunchKernelGGL((ransac_inlier_kernel<true>), dim3(n_pairs), dim3(256), 0, st, g);
@@ -1250,8 +1292,9 @@ extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, i
     if (n < min_n) return SFM_OK; // RANSAC.cpp:148-149
     const int64_t off[2] = {0, n};
     sfm_ransac_batch *b = nullptr;
+    // every row is scored when the caller asks for the per-row outputs
     int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, max_squared_error, success_prob, adaptive, loss, false,
-                        false, &b);
+                        false, &b, !counts_out && !toterr_out);
     int32_t bh = -1, bc = 0, it = 0;
     double be = 0, pose12[12];
     if (rc == SFM_OK) rc = sfm_ransac_batch_best(b, &bh, &bc, &be, pose12, &it);

@@ -216,3 +216,38 @@ def test_pretest_is_off_for_unusual_intrinsics(ctx, oracle):
     got = ctx.ransac_pair(tv["x"], tv["y"], K, S, max_sq_err=2.0, adaptive=False)
     exp = oracle.ransac(tv["x"], tv["y"], K, S, max_sq_err=2.0, adaptive=False)
     assert_same_run(got, exp)
+
+
+@pytest.mark.parametrize("first_slice", [256, 1024])
+def test_sliced_adaptive_batch_equals_one_pass(ctx, oracle, first_slice):
+    """With the adaptive cap on, a batch scores its sample rows in growing slices and pairs whose in-order
+    scan has stopped skip the later slices.  Winner, inlier list, error sum and iteration count must be
+    those of scoring every row (RANSAC.cpp:182-258 is an in-order scan, rows past the stop are never read)."""
+    H = 3000
+    cases = [(300, 0.9, 0.2), (500, 0.5, 0.3), (2000, 0.15, 0.5), (8, 1.0, 0.0), (5, 1.0, 0.0), (900, 0.7, 0.4)]
+    xs, ys, Ss, off = [], [], [], [0]
+    for k, (n, ratio, noise) in enumerate(cases):
+        tv = synth.two_view(max(n, 8), inlier_ratio=ratio, seed=100 + k, noise_px=noise)
+        xs.append(tv["x"][:n]); ys.append(tv["y"][:n])
+        Ss.append(synth.sample_table(max(n, 8), H, seed=200 + k) % max(n, 1))
+        off.append(off[-1] + n)
+    K = synth.default_K()
+    x, y, S = np.concatenate(xs), np.concatenate(ys), np.stack(Ss)
+    S[3] = np.tile(np.arange(8), (H, 1))  # the 8-point pair: every row is the same sample
+    ctx.set_option("hyps_per_launch", first_slice)
+    try:
+        b = ctx.ransac_batch(np.array(off), x, y, K, S, H, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        best = b.best()
+        ioff, inl = b.inliers()
+    finally:
+        ctx.set_option("hyps_per_launch", 0)
+    stopped_early = 0
+    for k, (n, _, _) in enumerate(cases):
+        e = oracle.ransac(x[off[k]:off[k + 1]], y[off[k]:off[k + 1]], K, S[k], max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        assert best["best_h"][k] == e["best_h"], k
+        assert best["iterations"][k] == e["iterations"], k
+        assert np.array_equal(inl[ioff[k]:ioff[k + 1]], e["inliers"]), k
+        if e["best_h"] >= 0:
+            assert best["toterr"][k] == e["toterr"][e["best_h"]], k
+        stopped_early += e["iterations"] < first_slice
+    assert stopped_early >= 2  # some pairs never see the later slices, others run all rows
