@@ -89,7 +89,9 @@ __global__ void ingest_norm_kernel(const float *__restrict__ desc32, const Image
         normA = __fadd_rn(normA, __fmul_rn(a[k], a[k]));
         bytes = bytes && a[k] >= 0.0f && a[k] <= 255.0f && a[k] == floorf(a[k]);
     }
-    const float s = __fsqrt_rn(normA);
+    // sqrtf, not __fsqrt_rn: the latter compiles to the bare v_sqrt_f32 (1 ulp); sqrtf is correctly rounded
+    // under -fhip-fp32-correctly-rounded-divide-sqrt, like std::sqrt on the host (match.hpp:45)
+    const float s = sqrtf(normA);
     norms[im.row32 + r] = s;
     const bool inRange = (s >= 1e-12f) && (s <= 1e12f);
     int f = bytes ? 0 : IMG_NOT_U8;

@@ -248,3 +248,13 @@ def test_32k_features_properties(ctx):
     assert set(map(tuple, ab)) == set(map(tuple, ba[:, ::-1]))
     assert res.stats()[1] == 0
     s.close()
+
+
+def test_norm_square_root_is_correctly_rounded(ctx, oracle):
+    """A descriptor matched with its copy at threshold 1.0: sim = n / (sqrtf(n) * sqrtf(n)) is 0.99999994 for
+    this n (match.hpp:45), so the reference rejects it; a square root that is one ulp low would accept."""
+    a = np.array([[163, 6, 172, 131, 41, 116, 2, 172, 91, 23, 172, 172, 124, 21, 172, 0, 172]], np.float32)
+    p = np.zeros((1, 2))
+    for thr in (1.0, 0.99999994, 0.9999999):
+        check_pair(ctx, oracle, a, p, a.copy(), p, thr)
+    assert len(ctx.match_pair(a, p, a.copy(), p, threshold=1.0)) == 0
