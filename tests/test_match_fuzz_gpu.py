@@ -52,3 +52,34 @@ def test_random_case(ctx, oracle, seed):
     assert np.array_equal(g1, e1), "matches1 differs"
     assert np.array_equal(g2, e2), "matches2 differs"
     assert np.array_equal(got, exp), "pair list differs"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SFM_FUZZ_BATCHES", "12"))))
+def test_random_batch(ctx, oracle, seed):
+    """Ragged image sets through the batch entry points: random counts (zeros included), random pair lists
+    with repeats and self pairs, several chunks, byte and float tables."""
+    rng = np.random.default_rng(5000 + seed)
+    n_img = int(rng.integers(2, 7))
+    counts = rng.choice([0, 1, 40, 256, 257, 600, 1100], n_img).astype(np.int32)
+    n = max(int(counts.max()), 1)
+    d, p, _ = synth.image_set(n_img, n, shared_frac=float(rng.uniform(0.1, 0.7)), seed=int(rng.integers(1 << 30)))
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)] + [np.zeros((0, 128), np.float32)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)] + [np.zeros((0, 2))])
+    pl = rng.integers(0, n_img, (int(rng.integers(1, 25)), 2)).astype(np.int32)
+    thr = float(rng.choice([0.95, 0.9, 0.6]))
+    gate = float(rng.choice([1e8, 120.0 ** 2]))
+    as_bytes = bool(rng.integers(2))
+    ctx.set_option("pairs_per_launch", int(rng.choice([1, 3, 2048])))
+    try:
+        s = ctx.imageset(counts, desc.astype(np.uint8) if as_bytes else desc, pts)
+        res = s.match(pl, threshold=thr, max_dist_sq=gate)
+        off, pairs = res.offsets(), res.pairs()
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    assert off[0] == 0 and off[-1] == len(pairs)
+    for k, (a, b) in enumerate(pl):
+        A, B = slice(starts[a], starts[a + 1]), slice(starts[b], starts[b + 1])
+        exp, _, _ = oracle.match(desc[A], pts[A], desc[B], pts[B], threshold=thr, max_dist_sq=gate)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp), f"pair {k} ({a},{b})"
+    s.close()
