@@ -105,3 +105,13 @@ def test_byte_table_equals_float_table(ctx, oracle):
         assert np.array_equal(pairsx[offx[k]:offx[k + 1]], exp2)
     for s in (sf, sb, sx):
         s.close()
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.0])
+def test_filtered_passes_at_benchmark_size(ctx, oracle, thr):
+    """8192 x 8192 with a loose threshold: every stage of the chain at full size (256 slices per pair,
+    both orientations of the filtered pass), against the restatement."""
+    ctx.set_option("sim_variant", INT8_BOUND)
+    d, p, _ = synth.image_set(2, 8192, seed=13)
+    (cand, cells, filtered, _), n = run(ctx, oracle, d[:8192], p[:8192], d[8192:], p[8192:], thr, 500.0 ** 2)
+    assert filtered == 1 and cells == 0 and n > 2000 and cand < 8192 * 64
