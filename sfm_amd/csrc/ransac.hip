@@ -584,17 +584,30 @@ __device__ int safe_cast_to_int(double v) // RANSAC.cpp:14-32
     return (int)v;
 }
 
-#define SEL_TILE 2048
+// The reference's loop (RANSAC.cpp:182-258) visits the sample rows in order, keeps the row with the
+// most inliers (then the smaller error sum, then the earlier row), lowers its iteration cap whenever
+// the kept row changes, and stops at the first row whose index has reached the cap.  The cap
+// depends only on the largest inlier count seen so far and never rises, so the scan parallelises:
+// a prefix maximum of the counts gives every row the cap in force when the loop reaches it, the
+// first row at or past its cap is where the loop stops, and the kept row is the lexicographic best
+// of the rows before that.  One block per pair; the state is carried from phase to phase.
+__device__ __forceinline__ int iteration_cap(const RansacArgs &g, int bestCount, int n)
+{
+    if (!g.adaptive || bestCount <= 0) return g.H;
+    const double inlierRatio = (double)bestCount / (double)n; // RANSAC.cpp:245-258
+    const double succesProb = pow(inlierRatio, 8.0);
+    if (!(succesProb >= 1e-6)) return g.H;
+    return min(g.H, safe_cast_to_int(ceil(log(1. - g.successProb) / log(1 - succesProb))));
+}
+
 __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
 {
-    __shared__ int sc[SEL_TILE];
-    __shared__ double se[SEL_TILE];
-    __shared__ int sDone;
+    __shared__ int sMax[256];
+    __shared__ int sStop;
+    __shared__ int sC[256], sH[256];
+    __shared__ double sE[256];
     const int p = blockIdx.x, tid = threadIdx.x;
     const int n = (int)(g.corrOff[p + 1] - g.corrOff[p]);
-    int maxIter = g.H, iterationsDone = 0, bestCount = 0, best = -1;
-    double bestError = INFINITY;
-    if (tid == 0) sDone = 0;
     if (n < 8) { // RANSAC.cpp:148-149
         if (tid == 0) {
             g.bestH[p] = -1;
@@ -606,55 +619,93 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
         return;
     }
     if (!g.active[p]) return;
-    if (g.hBegin > 0) { // resume the scan where the previous phase left it
-        maxIter = g.maxIter[p];
-        iterationsDone = g.iterations[p];
+    // state at the start of this phase
+    int capIn = g.H, bestCount = 0, best = -1;
+    double bestError = INFINITY;
+    if (g.hBegin > 0) {
+        capIn = g.maxIter[p];
         bestCount = g.bestCount[p];
         best = g.bestH[p];
         bestError = g.bestErr[p];
     }
-    for (int t0 = g.hBegin; t0 < g.hEnd; t0 += SEL_TILE) {
+    const int rows = g.hEnd - g.hBegin;
+    const int seg = (rows + 255) / 256;
+    const int q0 = g.hBegin + min(rows, tid * seg), q1 = g.hBegin + min(rows, (tid + 1) * seg);
+    const int *cnt = g.counts + (size_t)p * g.H;
+    const double *err = g.toterr + (size_t)p * g.H;
+
+    // largest count of this thread's rows, then the exclusive prefix maximum over threads
+    int local = 0;
+    for (int q = q0; q < q1; q++) local = max(local, cnt[q]);
+    sMax[tid] = local;
+    if (tid == 0) sStop = g.hEnd;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = (tid >= d) ? sMax[tid - d] : 0;
         __syncthreads();
-        if (sDone) break;
-        const int m = min(SEL_TILE, g.hEnd - t0);
-        for (int q = tid; q < m; q += 256) {
-            sc[q] = g.counts[(size_t)p * g.H + t0 + q];
-            se[q] = g.toterr[(size_t)p * g.H + t0 + q];
+        sMax[tid] = max(sMax[tid], v);
+        __syncthreads();
+    }
+    int running = max(bestCount, tid ? sMax[tid - 1] : 0);
+
+    // the first row that the loop does not reach: its index is at or past the cap in force
+    int cap = min(capIn, iteration_cap(g, running, n));
+    for (int q = q0; q < q1; q++) {
+        if (q >= cap) {
+            atomicMin(&sStop, q);
+            break;
         }
-        __syncthreads();
-        if (tid == 0) {
-            for (int q = 0; q < m; q++) {
-                if (iterationsDone >= maxIter) {
-                    sDone = 1;
-                    break;
-                }
-                iterationsDone++;
-                const int c = sc[q];
-                const double e = se[q];
-                if (c > 0 && (c > bestCount || (c == bestCount && e < bestError))) {
-                    bestError = e;
-                    bestCount = c;
-                    best = t0 + q;
-                    if (g.adaptive) {
-                        const double inlierRatio = (double)bestCount / (double)n;
-                        const double succesProb = pow(inlierRatio, 8.0);
-                        if (succesProb >= 1e-6) {
-                            const int newMax = safe_cast_to_int(ceil(log(1. - g.successProb) / log(1 - succesProb)));
-                            if (newMax < maxIter) maxIter = newMax;
-                        }
-                    }
-                }
-            }
+        const int c = cnt[q];
+        if (c > running) {
+            running = c;
+            cap = min(cap, iteration_cap(g, running, n));
         }
     }
+    __syncthreads();
+    const int stop = sStop;
+
+    // best of the rows before the stop: more inliers, then smaller error sum, then earlier row
+    int bc = 0, bh = -1;
+    double be = INFINITY;
+    for (int q = q0; q < min(q1, stop); q++) {
+        const int c = cnt[q];
+        const double e = err[q];
+        if (c > 0 && (c > bc || (c == bc && e < be))) {
+            bc = c;
+            be = e;
+            bh = q;
+        }
+    }
+    sC[tid] = bc;
+    sE[tid] = be;
+    sH[tid] = bh;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (tid < d) { // full ties go to the earlier row, wherever the tree has moved it
+            const int c = sC[tid + d];
+            const double e = sE[tid + d];
+            if (c > 0 && (c > sC[tid] || (c == sC[tid] && (e < sE[tid] || (e == sE[tid] && sH[tid + d] < sH[tid]))))) {
+                sC[tid] = c;
+                sE[tid] = e;
+                sH[tid] = sH[tid + d];
+            }
+        }
+        __syncthreads();
+    }
     if (tid == 0) {
+        if (sC[0] > 0 && (sC[0] > bestCount || (sC[0] == bestCount && sE[0] < bestError))) {
+            bestCount = sC[0];
+            bestError = sE[0];
+            best = sH[0];
+        }
+        const int capOut = min(capIn, iteration_cap(g, bestCount, n));
         g.bestH[p] = best;
         g.bestCount[p] = bestCount;
         g.bestErr[p] = bestError;
-        g.iterations[p] = iterationsDone;
-        g.maxIter[p] = maxIter;
+        g.iterations[p] = stop;
+        g.maxIter[p] = capOut;
         // the scan goes on iff it consumed this phase without reaching its cap and rows remain
-        g.active[p] = (iterationsDone < maxIter && g.hEnd < g.H) ? 1 : 0;
+        g.active[p] = (stop == g.hEnd && stop < capOut && g.hEnd < g.H) ? 1 : 0;
     }
 }
 
