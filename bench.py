@@ -215,15 +215,17 @@ def measured_traffic(pairs_per_launch, bound="int8"):
 def bench_pipeline(ctx, args):
     """Stand-in for the reference's default run (main.cpp:49-58: 27 frames, consecutive pairs, threshold
     0.95, pixel gate 100^2, 8192 hypotheses, maxSquaredError 1, successProb 0.999) with everything
-    resident on the device: match -> normalised correspondences -> RANSAC -> refit on the inliers."""
-    from sfm_amd import capi, synth
+    resident on the device: match -> normalised correspondences -> RANSAC -> refit on the inliers -> scale chain and
+    point average (its track ids come from the host, as in the reference's Scene)."""
+    from sfm_amd import capi, synth, tracks
     frames, feats, H = 27, args.features, 8192
     desc, pts, counts, _ = synth.frame_sequence(frames, feats, seed=4242)
     K = synth.default_K()
     pl = np.stack([np.arange(frames - 1), np.arange(1, frames)], axis=1).astype(np.int32)
     s = ctx.imageset(counts, desc, pts)
     res = corr = batch = None
-    stage_ms = np.zeros(4)
+    ids = n_tracks = None
+    stage_ms = np.zeros(5)
     reps = max(1, args.steps)
     for it in range(reps + 1):
         t = [time.perf_counter()]
@@ -236,6 +238,11 @@ def bench_pipeline(ctx, args):
         lib_rc = capi.lib().sfm_ransac_batch_refit(batch._h)
         ctx.check(lib_rc)
         ctx.synchronize(); t.append(time.perf_counter())
+        if ids is None:  # host bookkeeping of the reference's Scene, outside the timed stages
+            ids, n_tracks = tracks.assign_track_ids(pl, res.offsets(), res.pairs(), counts)
+            t[-1] = time.perf_counter()
+        chain = batch.scale_chain(ids, n_tracks=n_tracks)
+        t.append(time.perf_counter())
         if it > 0:  # first round warms up allocations
             stage_ms += np.diff(t) * 1e3
     stage_ms /= reps
@@ -244,10 +251,11 @@ def bench_pipeline(ctx, args):
     out = {
         "workload": f"{frames} synthetic frames x {feats} features, {frames - 1} consecutive pairs, {H} hypotheses per pair",
         "ms": {"match": round(stage_ms[0], 3), "correspondences": round(stage_ms[1], 3),
-               "ransac": round(stage_ms[2], 3), "refit": round(stage_ms[3], 3), "total": round(total, 3)},
+               "ransac": round(stage_ms[2], 3), "refit": round(stage_ms[3], 3), "chain": round(stage_ms[4], 3), "total": round(total, 3)},
         "pairs_per_s": round((frames - 1) / (total * 1e-3), 1),
         "matches_per_pair": round(res.total() / (frames - 1), 1),
         "mean_inliers": float(np.mean(best["count"])),
+        "tracks": int(n_tracks), "points_averaged": int((chain["counts"] > 1).sum()),
     }
     s.close()
     return out

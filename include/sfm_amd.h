@@ -69,7 +69,10 @@ const char *sfm_version(void);
  * bound; 2..5 = ablations that give wrong results and exist for timing only),
  * "ransac_filter" (1 = skip evaluations the
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
- * everything; results are identical).  Returns SFM_ERR_INVALID_ARG for an
+ * everything; results are identical), "chain_table_entries" (entries of the
+ * scale chain's (step, track) table, default 2^26; a sequence that needs more
+ * goes through in windows of steps; results are identical).
+ * Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */
 int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);
 
@@ -250,6 +253,44 @@ int sfm_ransac_batch_run_corr(sfm_ctx *ctx, sfm_corr *c, const double *K, int n_
                               double max_squared_error, double success_prob, int adaptive, int loss,
                               sfm_ransac_batch **batch_inout);
 void sfm_corr_destroy(sfm_corr *c);
+
+/* ---- scale chaining and running point average ------------------------------
+ * Replaces the tail of Scene::solveForLastAddedFrame, scene.cpp:301-421, for a
+ * whole sequence at once (geometry only; the colour average of scene.cpp:377,
+ * :394-407 needs the images).  Step s joins frames s and s + 1 and brings the
+ * two-view solution of that pair: pose (column-major 4x4, m_frame23.pose), the
+ * triangulated points in the older camera's frame (m_frame23.points) and the
+ * track id of each point (m_trackIndices23), distinct inside a step (the
+ * reference keeps them ascending; the result does not depend on their order).
+ * CSR over steps: step s owns rows offsets[s] .. offsets[s+1].
+ *   s > 0: ratios |pose12 * P12| / |P23| over the tracks both steps hold, both
+ *          lengths in (0.1, 100); with at least 5 ratios their median (element
+ *          n/2 in ascending order, getMedian scene.cpp:486-493) multiplies the
+ *          accumulated scale when it lies in [0.1, 10)          (scene.cpp:301-348)
+ *   view = pose, translation * scale, clamped to max_translation  (:356-365)
+ *   points with z >= 0: global = accPose * (scale * P); first sighting of a
+ *          track stores it, later ones within 50 of the mean update the
+ *          running mean and count                                 (:367-411)
+ *   accPose *= view^-1, appended to the extrinsics                (:421)
+ * Outputs (host, any may be NULL): extrinsics_out[n_steps+1][16] (entry 0 is
+ * start_pose16, scene.cpp:181), points3d_out[n_tracks][3] (zeros for tracks
+ * never seen), counts_out[n_tracks], acc_scale_out[n_steps] (scale used by
+ * step s).  A track id outside [0, n_tracks), or one that occurs twice in a
+ * step, is refused (SFM_ERR_INVALID_ARG).
+ */
+int sfm_scale_chain(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int32_t *track_ids,
+                    const double *points, const double *poses16, const double *start_pose16,
+                    double max_translation, int n_tracks, double *extrinsics_out,
+                    double *points3d_out, int32_t *counts_out, double *acc_scale_out);
+/* Same, reading poses and points of the steps from a refitted RANSAC batch
+ * without leaving the device (pair p of the batch = step p; its point set is
+ * the refit's: the inlier list when that has at least 8 entries, else all
+ * correspondences, else none).  corr_track_ids[total]: the track id of every
+ * correspondence of the batch (host), distinct inside a pair. */
+int sfm_scale_chain_refit(sfm_ransac_batch *b, const int32_t *corr_track_ids,
+                          const double *start_pose16, double max_translation, int n_tracks,
+                          double *extrinsics_out, double *points3d_out, int32_t *counts_out,
+                          double *acc_scale_out);
 
 #ifdef __cplusplus
 }

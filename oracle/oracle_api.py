@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libsfm_oracle.so")
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
@@ -61,6 +62,9 @@ def lib() -> C.CDLL:
     L.sfm_oracle_fit_hypotheses.argtypes = [_f64p, _f64p, _i32p, C.c_int, _f64p, _i32p]
     L.sfm_oracle_normalize_points.argtypes = [_f64p, _f64p, C.c_int, _f64p]
     L.sfm_oracle_sample_table.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.c_int, _i32p]
+    L.sfm_oracle_scale_chain.argtypes = [C.c_int, _i64p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int,
+                                         _f64p, _f64p, _i32p, _f64p]
+    L.sfm_oracle_scale_chain.restype = C.c_int
     L.sfm_oracle_sample_table.restype = None
     _lib = L
     return L
@@ -215,3 +219,27 @@ def sample_table(n: int, n_hyp: int, seed: int, pair_index: int) -> np.ndarray:
     out = np.zeros((max(n_hyp, 1), 8), np.int32)
     lib().sfm_oracle_sample_table(int(n), int(n_hyp), int(seed), int(pair_index), out)
     return out[:n_hyp]
+
+
+def scale_chain(offsets, track_ids, points, poses, start_pose=None, max_translation=15.0, n_tracks=0):
+    """Scale chaining + running point average (scene.cpp:301-421); same layout as the device call."""
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    S = len(offsets) - 1
+    pad = lambda a, shape, dt: a if a.size else np.zeros(shape, dt)
+    track_ids = pad(np.ascontiguousarray(track_ids, np.int32), 1, np.int32)
+    points = pad(np.ascontiguousarray(points, np.float64).reshape(-1, 3), (1, 3), np.float64)
+    poses_c = pad(np.ascontiguousarray(np.asarray(poses, np.float64).reshape(S, 4, 4).transpose(0, 2, 1)), (1, 4, 4),
+                  np.float64)
+    start = np.eye(4) if start_pose is None else np.asarray(start_pose, np.float64)
+    start_c = np.ascontiguousarray(start.T)
+    extr = np.zeros((S + 1, 16))
+    pts = np.zeros((max(n_tracks, 1), 3))
+    cnt = np.zeros(max(n_tracks, 1), np.int32)
+    scale = np.zeros(max(S, 1))
+    rc = lib().sfm_oracle_scale_chain(S, offsets, track_ids, points.reshape(-1), poses_c.reshape(-1),
+                                      start_c.reshape(-1), float(max_translation), int(n_tracks), extr.reshape(-1),
+                                      pts.reshape(-1), cnt, scale)
+    if rc != 0:
+        raise MemoryError("scale chain")
+    return dict(extrinsics=extr.reshape(S + 1, 4, 4).transpose(0, 2, 1).copy(), points3d=pts[:n_tracks],
+                counts=cnt[:n_tracks], scale=scale[:S])

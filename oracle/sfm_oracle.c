@@ -940,3 +940,155 @@ void sfm_oracle_sample_table(int64_t n, int n_hyp, uint64_t seed, int pair_index
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Scale chaining and running point average of Scene::solveForLastAddedFrame, scene.cpp:301-421
+ * (geometry only: the colour average of :378,:394-407 needs the images).
+ *
+ * Step s joins frames s and s + 1.  Its inputs are what the refit on the inliers produced for that
+ * pair: the ascending track ids of its points (m_trackIndices23), the points in the older camera's
+ * frame (m_frame23.points) and the pose (m_frame23.pose, column-major 4x4).  CSR over steps.
+ * State: accumulated scale (1), accumulated pose (start_pose16), per-track running mean and count.
+ * extrinsics_out[0] = start pose (scene.cpp:181), extrinsics_out[s + 1] = pose after step s (:421).
+ *
+ * Eigen's fixed-size products and Matrix4::inverse() are restated with a stated operation order
+ * (rows as sums left to right; adjugate / determinant by 2x2 sub-determinants), so parity with the
+ * reference is to rounding, not bitwise.
+ * --------------------------------------------------------------------------------------------- */
+static void mat4_mul(const double *A, const double *B, double *C) /* column-major */
+{
+    double T[16];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            T[r + 4 * c] = ((A[r] * B[4 * c] + A[r + 4] * B[1 + 4 * c]) + A[r + 8] * B[2 + 4 * c]) + A[r + 12] * B[3 + 4 * c];
+    memcpy(C, T, sizeof T);
+}
+
+static void mat4_inverse(const double *m, double *inv) /* column-major; adjugate / determinant */
+{
+#define M(r, c) m[(r) + 4 * (c)]
+    const double s0 = M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1);
+    const double s1 = M(0, 0) * M(1, 2) - M(1, 0) * M(0, 2);
+    const double s2 = M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3);
+    const double s3 = M(0, 1) * M(1, 2) - M(1, 1) * M(0, 2);
+    const double s4 = M(0, 1) * M(1, 3) - M(1, 1) * M(0, 3);
+    const double s5 = M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3);
+    const double c5 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3);
+    const double c4 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3);
+    const double c3 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2);
+    const double c2 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3);
+    const double c1 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2);
+    const double c0 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1);
+    const double det = ((((s0 * c5 - s1 * c4) + s2 * c3) + s3 * c2) - s4 * c1) + s5 * c0;
+    const double id = 1.0 / det;
+    double b[16];
+#define B_(r, c) b[(r) + 4 * (c)]
+    B_(0, 0) = ((M(1, 1) * c5 - M(1, 2) * c4) + M(1, 3) * c3) * id;
+    B_(0, 1) = ((-M(0, 1) * c5 + M(0, 2) * c4) - M(0, 3) * c3) * id;
+    B_(0, 2) = ((M(3, 1) * s5 - M(3, 2) * s4) + M(3, 3) * s3) * id;
+    B_(0, 3) = ((-M(2, 1) * s5 + M(2, 2) * s4) - M(2, 3) * s3) * id;
+    B_(1, 0) = ((-M(1, 0) * c5 + M(1, 2) * c2) - M(1, 3) * c1) * id;
+    B_(1, 1) = ((M(0, 0) * c5 - M(0, 2) * c2) + M(0, 3) * c1) * id;
+    B_(1, 2) = ((-M(3, 0) * s5 + M(3, 2) * s2) - M(3, 3) * s1) * id;
+    B_(1, 3) = ((M(2, 0) * s5 - M(2, 2) * s2) + M(2, 3) * s1) * id;
+    B_(2, 0) = ((M(1, 0) * c4 - M(1, 1) * c2) + M(1, 3) * c0) * id;
+    B_(2, 1) = ((-M(0, 0) * c4 + M(0, 1) * c2) - M(0, 3) * c0) * id;
+    B_(2, 2) = ((M(3, 0) * s4 - M(3, 1) * s2) + M(3, 3) * s0) * id;
+    B_(2, 3) = ((-M(2, 0) * s4 + M(2, 1) * s2) - M(2, 3) * s0) * id;
+    B_(3, 0) = ((-M(1, 0) * c3 + M(1, 1) * c1) - M(1, 2) * c0) * id;
+    B_(3, 1) = ((M(0, 0) * c3 - M(0, 1) * c1) + M(0, 2) * c0) * id;
+    B_(3, 2) = ((-M(3, 0) * s3 + M(3, 1) * s1) - M(3, 2) * s0) * id;
+    B_(3, 3) = ((M(2, 0) * s3 - M(2, 1) * s1) + M(2, 2) * s0) * id;
+#undef B_
+#undef M
+    memcpy(inv, b, sizeof b);
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    const double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* (pose * p.homogeneous()).head<3>() */
+static void pose_apply(const double *P, const double *p, double *out)
+{
+    for (int r = 0; r < 3; r++)
+        out[r] = ((P[r] * p[0] + P[r + 4] * p[1]) + P[r + 8] * p[2]) + P[r + 12];
+}
+
+int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *track_ids, const double *points,
+                           const double *poses16, const double *start_pose16, double max_translation, int n_tracks,
+                           double *extrinsics_out, double *points3d_out, int32_t *counts_out, double *acc_scale_out)
+{
+    double accScale = 1.0, accPose[16];
+    memcpy(accPose, start_pose16, sizeof accPose);
+    memcpy(extrinsics_out, accPose, sizeof accPose);
+    for (int t = 0; t < n_tracks; t++) {
+        points3d_out[3 * t] = points3d_out[3 * t + 1] = points3d_out[3 * t + 2] = 0.0;
+        counts_out[t] = 0;
+    }
+    double *ratios = (double *)malloc(sizeof(double) * (size_t)(offsets[n_steps] > 0 ? offsets[n_steps] : 1));
+    if (!ratios) return -1;
+    for (int s = 0; s < n_steps; s++) {
+        const int64_t b23 = offsets[s], n23 = offsets[s + 1] - b23;
+        if (s > 0) { /* scene.cpp:301-354 */
+            const int64_t b12 = offsets[s - 1], n12 = offsets[s] - b12;
+            const double *pose12 = poses16 + 16 * (s - 1);
+            int64_t idx12 = 0, nr = 0;
+            for (int64_t idx23 = 0; idx23 < n23; idx23++) {
+                const int cur = track_ids[b23 + idx23];
+                while (idx12 < n12 && track_ids[b12 + idx12] < cur) idx12++;
+                if (idx12 >= n12) break;
+                if (track_ids[b12 + idx12] == cur) {
+                    double q[3];
+                    pose_apply(pose12, points + 3 * (b12 + idx12), q);
+                    const double *p23 = points + 3 * (b23 + idx23);
+                    const double dist12 = sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+                    const double dist23 = sqrt((p23[0] * p23[0] + p23[1] * p23[1]) + p23[2] * p23[2]);
+                    if (dist23 > 0.1 && dist12 > 0.1 && dist23 < 100.0 && dist12 < 100.0) ratios[nr++] = dist12 / dist23;
+                }
+            }
+            if (nr >= 5) {
+                qsort(ratios, (size_t)nr, sizeof(double), cmp_double); /* getMedian, scene.cpp:486-493: element n/2 */
+                const double rel = ratios[nr / 2];
+                if (rel >= 0.1 && rel < 10) accScale *= rel;
+            }
+        }
+        if (acc_scale_out) acc_scale_out[s] = accScale;
+        double view[16];
+        memcpy(view, poses16 + 16 * s, sizeof view);
+        for (int r = 0; r < 3; r++) view[r + 12] *= accScale; /* :356-357 */
+        const double len = sqrt((view[12] * view[12] + view[13] * view[13]) + view[14] * view[14]);
+        if (len > max_translation) { /* :359-365 */
+            const double f = max_translation / len;
+            for (int r = 0; r < 3; r++) view[r + 12] *= f;
+        }
+        for (int64_t j = 0; j < n23; j++) { /* :367-411 */
+            const int t = track_ids[b23 + j];
+            const double *p = points + 3 * (b23 + j);
+            if (p[2] < 0 || t < 0 || t >= n_tracks) continue;
+            const double sp[3] = {accScale * p[0], accScale * p[1], accScale * p[2]};
+            double g[3];
+            pose_apply(accPose, sp, g);
+            double *cur = points3d_out + 3 * t;
+            if (counts_out[t] == 0) {
+                cur[0] = g[0]; cur[1] = g[1]; cur[2] = g[2];
+                counts_out[t] = 1;
+            } else {
+                const double d0 = cur[0] - g[0], d1 = cur[1] - g[1], d2 = cur[2] - g[2];
+                if (sqrt((d0 * d0 + d1 * d1) + d2 * d2) < 50.0) {
+                    const double N1 = (double)(counts_out[t] + 1);
+                    for (int r = 0; r < 3; r++) cur[r] = cur[r] + (g[r] - cur[r]) / N1;
+                    counts_out[t]++;
+                }
+            }
+        }
+        double inv[16];
+        mat4_inverse(view, inv); /* :421 */
+        mat4_mul(accPose, inv, accPose);
+        memcpy(extrinsics_out + 16 * (s + 1), accPose, sizeof accPose);
+    }
+    free(ratios);
+    return 0;
+}

@@ -5,8 +5,10 @@ exception is raised.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -33,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
-    "sfm_ransac_batch_run_corr", "sfm_corr_destroy",
+    "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
 ]
 
 
@@ -103,9 +105,21 @@ def lib() -> C.CDLL:
     L.sfm_corr_sample_table.argtypes = [vp, i32, C.c_uint64, P(vp), vp]
     L.sfm_ransac_batch_run_corr.argtypes = [vp, vp, vp, i32, C.c_uint64, f64, f64, i32, i32, P(vp)]
     L.sfm_corr_destroy.argtypes = [vp]
+    L.sfm_scale_chain.argtypes = [vp, i32, vp, vp, vp, vp, vp, f64, i32, vp, vp, vp, vp]
+    L.sfm_scale_chain_refit.argtypes = [vp, vp, vp, f64, i32, vp, vp, vp, vp]
     L.sfm_corr_destroy.restype = None
     _lib = L
     return L
+
+
+def _chain_outputs(S, n_tracks):
+    return (np.zeros((S + 1, 16)), np.zeros((max(n_tracks, 1), 3)), np.zeros(max(n_tracks, 1), np.int32),
+            np.zeros(max(S, 1)))
+
+
+def _chain_result(out, S, n_tracks):
+    return dict(extrinsics=out[0].reshape(S + 1, 4, 4).transpose(0, 2, 1).copy(), points3d=out[1][:n_tracks],
+                counts=out[2][:n_tracks], scale=out[3][:S])
 
 
 def _ptr(a):
@@ -114,10 +128,30 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+# Every live wrapper, so that interpreter exit releases device objects before their contexts and
+# both before the HIP runtime unloads (a handle freed after that aborts the process).
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    objs = list(_live)
+    for want_ctx in (False, True):
+        for o in objs:
+            if isinstance(o, Context) == want_ctx:
+                try:
+                    o.close()
+                except Exception:
+                    pass
+
+
+atexit.register(_close_all)
+
+
 class Context:
     """One device context (HIP stream + workspace)."""
 
     def __init__(self, device: int = 0):
+        _live.add(self)
         self._h = C.c_void_p()
         rc = lib().sfm_ctx_create(int(device), C.byref(self._h))
         if rc != OK:
@@ -213,6 +247,23 @@ class Context:
         self.check(lib().sfm_eight_point_fit(self._h, _ptr(x), _ptr(y), len(x), _ptr(samples), H, _ptr(pose12)))
         return pose12[:H]
 
+    def scale_chain(self, offsets, track_ids, points, poses, start_pose=None, max_translation=15.0, n_tracks=0):
+        """Scale chaining + running point average over a frame sequence (scene.cpp:301-421).
+        offsets [S+1], track_ids [total], points [total,3], poses [S,4,4].  Returns a dict with
+        extrinsics [S+1,4,4], points3d [n_tracks,3], counts [n_tracks], scale [S]."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        S = len(offsets) - 1
+        track_ids = np.ascontiguousarray(track_ids, np.int32)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        poses_c = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(S, 4, 4).transpose(0, 2, 1))
+        start = np.eye(4) if start_pose is None else np.asarray(start_pose, np.float64)
+        start_c = np.ascontiguousarray(start.T)
+        out = _chain_outputs(S, n_tracks)
+        self.check(lib().sfm_scale_chain(self._h, S, _ptr(offsets), _ptr(track_ids), _ptr(points), _ptr(poses_c),
+                                         _ptr(start_c), float(max_translation), int(n_tracks), _ptr(out[0]),
+                                         _ptr(out[1]), _ptr(out[2]), _ptr(out[3])))
+        return _chain_result(out, S, n_tracks)
+
     def eight_point_algorithm(self, x, y):
         """eightPointAlgorithm (eightPoint.cpp:57-223): (pose 4x4, points [n,3])."""
         x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
@@ -249,6 +300,7 @@ class ImageSet:
     """Descriptor/point table resident in HBM (sfm_imageset_*)."""
 
     def __init__(self, ctx: Context, counts, desc, pts, dim=None):
+        _live.add(self)
         self.ctx = ctx
         counts = np.ascontiguousarray(counts, np.int32)
         self._h = C.c_void_p()
@@ -299,6 +351,7 @@ class MatchResult:
     """CSR match lists of a batch, resident on the device until fetched."""
 
     def __init__(self, ctx: Context):
+        _live.add(self)
         self.ctx = ctx
         self._h = C.c_void_p()
         self.n_pairs = 0
@@ -349,6 +402,7 @@ class MatchResult:
 
 class RansacBatch:
     def __init__(self, ctx: Context):
+        _live.add(self)
         self.ctx = ctx
         self._h = C.c_void_p()
         self.n_pairs = 0
@@ -400,11 +454,28 @@ class RansacBatch:
             pass
 
 
+def _batch_scale_chain(self, corr_track_ids, start_pose=None, max_translation=15.0, n_tracks=0):
+    """Scale chaining over the refitted pairs of this batch (pair p = step p), device to device.
+    corr_track_ids: the track id of every correspondence of the batch."""
+    ids = np.ascontiguousarray(corr_track_ids, np.int32)
+    start = np.eye(4) if start_pose is None else np.asarray(start_pose, np.float64)
+    start_c = np.ascontiguousarray(start.T)
+    S = self.n_pairs
+    out = _chain_outputs(S, n_tracks)
+    self.ctx.check(lib().sfm_scale_chain_refit(self._h, _ptr(ids), _ptr(start_c), float(max_translation),
+                                               int(n_tracks), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3])))
+    return _chain_result(out, S, n_tracks)
+
+
+RansacBatch.scale_chain = _batch_scale_chain
+
+
 class Correspondences:
     """Normalised correspondences of every pair of a match result, resident on the device
     (sfm_corr_*): the hand-off from matching to RANSAC."""
 
     def __init__(self, ctx: Context, imageset: ImageSet, result: MatchResult, K, reuse: "Correspondences" = None):
+        _live.add(self)
         self.ctx = ctx
         self._h = reuse._h if reuse is not None else C.c_void_p()
         if reuse is not None:

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -25,7 +26,11 @@ struct sfm_ctx {
     std::vector<Span> span_pool[2]; // events are created once and reused
     size_t span_used[2] = {0, 0};
     int n_cus = 256;
+    // scale chain: work space kept between calls, and the size of its (step, track) table
+    struct ChainScratch *chain = nullptr;
+    int64_t chain_table_entries = (int64_t)1 << 26;
 };
+void sfm_chain_scratch_free(sfm_ctx *ctx);
 
 #define SFM_FAIL(ctx, code, ...)                                   \
     do {                                                           \
@@ -109,5 +114,20 @@ hipError_t sfm_span_begin(sfm_ctx *ctx, int which);
 hipError_t sfm_span_end(sfm_ctx *ctx, int which);
 void sfm_span_reset(sfm_ctx *ctx, int which);
 int sfm_num_sim_variants();
+
+// Device-side view of a RANSAC batch after its refit (read by the scale chain).
+struct RefitView {
+    int n_pairs;
+    int64_t total;
+    const int64_t *corrOffHost; // [n_pairs + 1], host
+    const int64_t *corrOff;     // device from here on
+    const int32_t *inlCount;
+    const int64_t *inlOff;
+    const int32_t *inliers;
+    const double *pose16;
+    const int32_t *used;
+    const double *points;
+};
+int sfm_ransac_batch_refit_view(sfm_ransac_batch *b, RefitView *v, sfm_ctx **ctx_out);
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

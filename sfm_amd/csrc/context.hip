@@ -34,10 +34,9 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    sfm_chain_scratch_free(ctx);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int w = 0; w < 2; w++)
         for (auto &s : ctx->span_pool[w]) {
             (void)hipEventDestroy(s.a);
@@ -67,6 +66,9 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "hyps_per_launch")) {
         if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "hyps_per_launch must be >= 0");
         ctx->hyps_per_launch = value;
+    } else if (!strcmp(key, "chain_table_entries")) {
+        if (value < 2) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "chain_table_entries must be >= 2");
+        ctx->chain_table_entries = value;
     } else if (!strcmp(key, "ransac_filter")) {
         ctx->ransac_filter = value != 0;
     } else if (!strcmp(key, "sim_variant")) {

@@ -1026,6 +1026,8 @@ struct sfm_ransac_batch {
         inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter;
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
+    bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
+    std::vector<int64_t> corrOffHost; // the last run's offsets
 };
 
 extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
@@ -1078,6 +1080,9 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     b->H = n_hyp;
     b->total = total;
     b->scored = false;
+    b->refitted = false;
+    if (n_pairs > 0) b->corrOffHost.assign(corr_offsets, corr_offsets + n_pairs + 1);
+    else b->corrOffHost.assign(1, 0);
     sfm_span_reset(ctx, 1);
     hipStream_t st = ctx->stream;
     const size_t PH = (size_t)(n_pairs ? n_pairs : 1) * (size_t)(n_hyp ? n_hyp : 1);
@@ -1222,6 +1227,27 @@ extern "C" int sfm_ransac_batch_refit(sfm_ransac_batch *b)
     rf.points = b->refitPoints.as<double>();
     hipLaunchKernelGGL(ransac_refit_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->args, rf);
     SFM_HIP(ctx, hipGetLastError());
+    b->refitted = true;
+    return SFM_OK;
+}
+
+int sfm_ransac_batch_refit_view(sfm_ransac_batch *b, RefitView *v, sfm_ctx **ctx_out)
+{
+    if (!b || !v || !ctx_out) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    *ctx_out = ctx;
+    if (!b->scored || (!b->refitted && b->n_pairs > 0))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "refit: sfm_ransac_batch_refit has not run on this batch's result");
+    v->n_pairs = b->n_pairs;
+    v->total = b->total;
+    v->corrOffHost = b->corrOffHost.data();
+    v->corrOff = b->corrOff.as<int64_t>();
+    v->inlCount = b->inlCount.as<int32_t>();
+    v->inlOff = b->inlOff.as<int64_t>();
+    v->inliers = b->inliers.as<int32_t>();
+    v->pose16 = b->refitPose.as<double>();
+    v->used = b->refitUsed.as<int32_t>();
+    v->points = b->refitPoints.as<double>();
     return SFM_OK;
 }
 

@@ -266,3 +266,33 @@ def test_sample_table_generator(oracle):
         assert chi2 < (n - 1) + 5 * np.sqrt(2 * (n - 1))
     assert np.array_equal(np.sort(oracle.sample_table(8, 10, 1, 0), axis=1), np.tile(np.arange(8), (10, 1)))
     assert not oracle.sample_table(7, 10, 1, 0).any()
+
+
+# ---- scale chain ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,n_steps,n_tracks,kw", [
+    (1, 12, 500, {}), (2, 6, 120, dict(behind=0.3, far=0.2)), (3, 1, 30, {}), (4, 9, 4, {}),
+])
+def test_scale_chain_against_numpy(oracle, seed, n_steps, n_tracks, kw):
+    """The C restatement of scene.cpp:301-421 against an independent numpy one (rounding apart: numpy's
+    matrix products and inverse take another route)."""
+    from chain_cases import sequence, numpy_chain
+    off, ids, pts, poses = sequence(seed, n_steps, n_tracks, **kw)
+    start = np.eye(4)
+    start[:3, 3] = [1, 2, 3]
+    for cap in (15.0, 0.7):
+        got = oracle.scale_chain(off, ids, pts, poses, start_pose=start, max_translation=cap, n_tracks=n_tracks)
+        exp = numpy_chain(off, ids, pts, poses, start=start, max_translation=cap, n_tracks=n_tracks)
+        assert np.array_equal(got["counts"], exp["counts"])
+        for k in ("extrinsics", "points3d", "scale"):
+            assert np.allclose(got[k], exp[k], rtol=1e-11, atol=1e-11), k
+
+
+def test_scale_chain_median_is_upper(oracle):
+    """getMedian (scene.cpp:486-493) takes element n/2 of the ascending order: with six ratios the fourth."""
+    ids = np.arange(6, dtype=np.int32)
+    off = np.array([0, 6, 12], np.int64)
+    p12 = np.zeros((6, 3)); p12[:, 2] = [1, 2, 3, 4, 5, 6]
+    p23 = np.zeros((6, 3)); p23[:, 2] = 1.0
+    poses = np.stack([np.eye(4)] * 2)  # |pose12 * P12| = P12's depth
+    got = oracle.scale_chain(off, np.concatenate([ids, ids]), np.concatenate([p12, p23]), poses, n_tracks=6)
+    assert got["scale"][0] == 1.0 and got["scale"][1] == 4.0
