@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--ransac-hyps", type=int, default=4096)
     ap.add_argument("--bound", choices=sorted(BOUNDS), default="int8",
                     help="arithmetic of the matcher's similarity bound (the exact re-scoring is fp32 either way)")
+    ap.add_argument("--first-slice", type=int, default=0,
+                    help="rows of the first slice of adaptive RANSAC batches (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
@@ -68,6 +70,8 @@ def main():
     ctx = capi.Context(local_rank)
     sim_variant, bound_dtype, bound_peak = BOUNDS[args.bound]
     ctx.set_option("sim_variant", sim_variant)
+    if args.first_slice > 0:
+        ctx.set_option("hyps_per_launch", args.first_slice)
 
     # ---- workload: weak scaling, pairs_per_gpu fixed ---------------------------------------
     pairs_per_gpu = args.images * (args.images - 1) // 2

@@ -64,7 +64,11 @@ const char *sfm_version(void);
  * "pairs_per_launch" (default 2048), "hyps_per_launch" (rows of the first
  * slice of an adaptive RANSAC batch: rows are scored in slices growing by a
  * factor of four and pairs whose scan has stopped skip the later ones;
- * default 0 = sized to fill the device), "sim_variant"
+ * default 0 = 256 rows when the launch is small enough to be split over
+ * correspondences, else sized to fill the device), "ransac_split" (1 = a
+ * scoring launch with few blocks cuts every pair's correspondences over several
+ * blocks and adds the errors up in order in a second kernel, default; 0 = one
+ * block per 256 rows always; results are identical), "sim_variant"
  * (instance of the similarity kernel: 1 = int8 bound, the default; 0 = fp16
  * bound; 2..5 = ablations that give wrong results and exist for timing only),
  * "ransac_filter" (1 = skip evaluations the

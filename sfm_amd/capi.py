@@ -217,7 +217,10 @@ class Context:
 
     # ---- RANSAC ---------------------------------------------------------------------------
     def ransac_pair(self, x, y, K, samples, max_sq_err=10.0, success_prob=0.99, adaptive=True, min_n=8,
-                    loss=LOSS_REPROJECTION):
+                    loss=LOSS_REPROJECTION, per_row=True):
+        """solve::RANSAC for one pair.  per_row=False leaves out the per-hypothesis counts and error sums
+        (the reference does not return them); the library then scores rows in growing slices and stops
+        where the adaptive cap stops the reference's loop."""
         x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
         y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
         if len(x) != len(y):  # RANSAC.cpp:148
@@ -228,15 +231,16 @@ class Context:
         H, n = samples.shape[0], len(x)
         inl = np.zeros(max(n, 1), np.int32)
         pose = np.eye(4).reshape(-1, order="F").copy()
-        counts = np.zeros(max(H, 1), np.int32)
-        toterr = np.zeros(max(H, 1), np.float64)
+        counts = np.zeros(max(H, 1), np.int32) if per_row else None
+        toterr = np.zeros(max(H, 1), np.float64) if per_row else None
         cnt, best, iters = C.c_int(0), C.c_int(-1), C.c_int(0)
         self.check(lib().sfm_ransac_pair(self._h, _ptr(x), _ptr(y), n, _ptr(Kc), _ptr(samples), H, min_n,
                                          max_sq_err, success_prob, int(bool(adaptive)), loss, _ptr(inl), max(n, 1),
                                          C.byref(cnt), C.byref(best), _ptr(pose), _ptr(counts), _ptr(toterr),
                                          C.byref(iters)))
         return dict(inliers=inl[:cnt.value].copy(), best_h=best.value, pose=pose.reshape(4, 4, order="F").copy(),
-                    counts=counts[:H].copy(), toterr=toterr[:H].copy(), iterations=iters.value)
+                    counts=counts[:H].copy() if per_row else None, toterr=toterr[:H].copy() if per_row else None,
+                    iterations=iters.value)
 
     def eight_point_fit(self, x, y, samples):
         x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)

@@ -20,6 +20,7 @@ struct sfm_ctx {
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
     int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
+    int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };
@@ -28,9 +29,11 @@ struct sfm_ctx {
     int n_cus = 256;
     // scale chain: work space kept between calls, and the size of its (step, track) table
     struct ChainScratch *chain = nullptr;
+    sfm_ransac_batch *pair_batch = nullptr; // device buffers of the single-pair RANSAC entry points
     int64_t chain_table_entries = (int64_t)1 << 26;
 };
 void sfm_chain_scratch_free(sfm_ctx *ctx);
+void sfm_pair_batch_free(sfm_ctx *ctx);
 
 #define SFM_FAIL(ctx, code, ...)                                   \
     do {                                                           \

@@ -36,6 +36,7 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sfm_chain_scratch_free(ctx);
+    sfm_pair_batch_free(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int w = 0; w < 2; w++)
         for (auto &s : ctx->span_pool[w]) {
@@ -69,6 +70,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "chain_table_entries")) {
         if (value < 2) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "chain_table_entries must be >= 2");
         ctx->chain_table_entries = value;
+    } else if (!strcmp(key, "ransac_split")) {
+        ctx->ransac_split = value != 0;
     } else if (!strcmp(key, "ransac_filter")) {
         ctx->ransac_filter = value != 0;
     } else if (!strcmp(key, "sim_variant")) {

@@ -449,8 +449,14 @@ __device__ __forceinline__ f32x2 splat(float v)
 }
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int LOSS>
-__global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
+// SPLIT: the launch has too few (pair, 256-row) blocks to fill the device, so blockIdx.z cuts every
+// pair's correspondences into segments and a block scores its rows on one segment only.  A row's
+// inlier count and error sum must still accumulate in correspondence order (the sum is not
+// associative), so instead of accumulating, the block writes every cell of
+// errBuf[(correspondence, row)]: the error of an inlier, a negative NaN pattern otherwise, and
+// ransac_sum_kernel adds the inliers' errors up in order.
+template <int LOSS, bool SPLIT>
+__global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, double *__restrict__ errBuf)
 {
     __shared__ __attribute__((aligned(16))) double rec[SCORE_CH * REC_D];
     __shared__ unsigned short pend[SCORE_QCAP][256]; // per-lane queues of chunk-local correspondence indices
@@ -462,6 +468,17 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
     const int n = (int)(g.corrOff[p + 1] - base);
     if (!g.active[p]) return; // the pair's scan stopped in an earlier phase
     const bool active = h < g.hEnd;
+    int kBeg = 0, kEnd = n;
+    if (SPLIT) {
+        const int seg = (((n + (int)gridDim.z - 1) / (int)gridDim.z) + 1) & ~1;
+        kBeg = min(n, (int)blockIdx.z * seg);
+        kEnd = min(n, kBeg + seg);
+        if (kBeg >= kEnd) return;
+    }
+    const int rows = g.hEnd - g.hBegin;
+    double *errCol = SPLIT ? errBuf + (size_t)base * rows + (h - g.hBegin) : nullptr; // + k * rows
+    // a slice of fewer than 256 rows leaves whole waves without a row: they only help staging
+    const bool waveIdle = SPLIT && g.hBegin + (int)blockIdx.x * 256 + (tid & ~63) >= g.hEnd;
     Pose P;
     load_pose(g.pose12 + ((size_t)p * g.H + (active ? h : 0)) * 12, P);
     double E[3][3];
@@ -487,21 +504,28 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
     // A lane drains its queue in order, so its count and error sum still accumulate in
     // correspondence order (RANSAC.cpp:207-221).
     int npend = 0;
-    auto evaluate = [&](int kk) {
-        const double *r = rec + kk * REC_D;
-        const double e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
-        if (e < thr) { // RANSAC.cpp:216-220
+    int kChunk = 0; // first correspondence of the chunk in LDS
+    const double none = __longlong_as_double(-1ll); // negative NaN pattern: fails v >= 0
+    auto record = [&](int kk, double e) {
+        if (SPLIT) { // every (correspondence, row) cell is written exactly once
+            if (active) errCol[(size_t)(kChunk + kk) * rows] = (e < thr) ? e : none;
+        } else if (e < thr) { // RANSAC.cpp:216-220
             count++;
             tot += e;
         }
+    };
+    auto evaluate = [&](int kk) {
+        const double *r = rec + kk * REC_D;
+        record(kk, reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]));
     };
     auto drain = [&]() {
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < npend) != 0; i++)
             if (i < npend) evaluate(pend[i][tid]);
         npend = 0;
     };
-    for (int k0 = 0; k0 < n; k0 += SCORE_CH) {
-        const int m = min(SCORE_CH, n - k0);
+    for (int k0 = kBeg; k0 < kEnd; k0 += SCORE_CH) {
+        const int m = min(SCORE_CH, kEnd - k0);
+        kChunk = k0;
         const double2 *src = reinterpret_cast<const double2 *>(g.rec + (base + k0) * REC_D);
         for (int q = tid; q < m * (REC_D / 2); q += 256) reinterpret_cast<double2 *>(rec)[q] = src[q];
         __syncthreads();
@@ -519,14 +543,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
             }
             __syncthreads();
         }
-        if (LOSS == SFM_LOSS_SAMPSON) {
+        if (waveIdle) {
+        } else if (LOSS == SFM_LOSS_SAMPSON) {
             for (int kk = 0; kk < m; kk++) {
                 const double *r = rec + kk * REC_D;
-                const double e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
-                if (e < thr) {
-                    count++;
-                    tot += e;
-                }
+                record(kk, sampson_loss(K, E, r[0], r[1], r[2], r[3]));
             }
         } else if (!filterOn) {
             for (int kk = 0; kk < m; kk++) evaluate(kk);
@@ -559,7 +580,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
                 const bool skip0 = n2.x >= den2.x && m01.x >= g1.x && n2.x >= g2.x;
                 const bool skip1 = n2.y >= den2.y && m01.y >= g1.y && n2.y >= g2.y;
                 if (!skip0) pend[npend++][tid] = (unsigned short)kk;
-                if (!skip1 && kk + 1 < m) pend[npend++][tid] = (unsigned short)(kk + 1);
+                else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
+                if (kk + 1 < m) {
+                    if (!skip1) pend[npend++][tid] = (unsigned short)(kk + 1);
+                    else if (SPLIT && active) errCol[(size_t)(kChunk + kk + 1) * rows] = none;
+                }
                 // room for the next four: drain as soon as any lane of the wave holds more than four
                 if ((kk & 2) && __builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 4) != 0) drain();
             }
@@ -567,7 +592,77 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g)
         }
         __syncthreads();
     }
-    if (active) {
+    if (active && !SPLIT) {
+        g.counts[(size_t)p * g.H + h] = count;
+        g.toterr[(size_t)p * g.H + h] = tot;
+    }
+}
+
+// Second half of a split scoring launch: every row adds up its inliers' errors in correspondence
+// order (RANSAC.cpp:207-221) from the (correspondence, row) buffer.  The additions of a row form one
+// dependent chain, so the block's job is to keep them fed: R rows per block, all waves fetch tiles of
+// SUM_KT correspondences x R rows into registers (two tiles in flight) while the first wave adds up
+// the tile in LDS.  R = 64 when there are blocks enough to fill the device, 16 otherwise: a block pulls
+// what one CU's memory path delivers, so fewer rows per block means more CUs at work.
+#define SUM_THREADS 512
+#define SUM_KT 128
+template <int R>
+__global__ __launch_bounds__(SUM_THREADS) void ransac_sum_kernel(const RansacArgs g, const double *__restrict__ errBuf)
+{
+    __shared__ double tile[SUM_KT][R];
+    const int p = blockIdx.y;
+    if (!g.active[p]) return;
+    const int tid = threadIdx.x;
+    const int r = tid % R, sub = tid / R;   // row of the block, fetch slot
+    constexpr int SLOTS = SUM_THREADS / R;  // correspondences fetched side by side
+    constexpr int PER = SUM_KT / SLOTS;     // fetches of a thread per tile
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    const int rows = g.hEnd - g.hBegin;
+    const int hl = blockIdx.x * R + r;
+    const bool live = hl < rows;
+    const double *col = errBuf + (size_t)base * rows + (live ? hl : 0);
+    const double none = __longlong_as_double(-1ll);
+    double bufA[PER], bufB[PER];
+    auto fetch = [&](double (&buf)[PER], int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int k = k0 + sub + i * SLOTS;
+            buf[i] = (live && k < n) ? col[(size_t)k * rows] : none;
+        }
+    };
+    int count = 0;
+    double tot = 0.0;
+    auto consume = [&](double (&buf)[PER], int kNext) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) tile[sub + i * SLOTS][r] = buf[i];
+        __syncthreads();
+        if (kNext < n) fetch(buf, kNext);
+        if (tid < R) { // cells past the end of the pair hold the "none" pattern
+#pragma unroll 1
+            for (int kk = 0; kk < SUM_KT; kk += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = tile[kk + i][r];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const bool in = v[i] >= 0;
+                    // x + (-0.0) = x for every x this sum can hold, so the chain is one addition per cell
+                    tot = tot + (in ? v[i] : -0.0);
+                    count += in ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    fetch(bufA, 0);
+    if (SUM_KT < n) fetch(bufB, SUM_KT);
+    for (int k0 = 0; k0 < n; k0 += 2 * SUM_KT) {
+        consume(bufA, k0 + 2 * SUM_KT);
+        if (k0 + SUM_KT < n) consume(bufB, k0 + 3 * SUM_KT);
+    }
+    if (tid < R && live) {
+        const int h = g.hBegin + hl;
         g.counts[(size_t)p * g.H + h] = count;
         g.toterr[(size_t)p * g.H + h] = tot;
     }
@@ -1023,7 +1118,7 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf;
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
@@ -1037,9 +1132,21 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
-                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter};
+                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf};
     for (DevBuf *d : bufs) d->release();
     delete b;
+}
+
+// Segments per pair of a scoring launch over `rows` rows: more than one when the launch would leave
+// most of the device idle (too few (pair, 256-row) blocks) and its (correspondence, row) error buffer
+// stays moderate.
+static int split_factor(const sfm_ctx *ctx, int n_pairs, int rows, int64_t total)
+{
+    if (!ctx->ransac_split || n_pairs <= 0 || rows <= 0) return 1;
+    const int64_t blocks = (int64_t)n_pairs * ((rows + 255) / 256);
+    const size_t errBytes = (size_t)rows * (size_t)total * sizeof(double);
+    if (blocks >= 2 * ctx->n_cus || errBytes > ((size_t)1 << 31)) return 1;
+    return (int)std::max<int64_t>(1, std::min<int64_t>((4 * ctx->n_cus + blocks - 1) / blocks, total / n_pairs / 16));
 }
 
 static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
@@ -1169,8 +1276,13 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     SFM_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)b->active.p, 1, (size_t)n_pairs, st));
     std::vector<int> bounds{0};
     if (phased && adaptive && !fit_only) {
+        // The first slice is as small as its launch can be made efficient: 256 rows (one block of rows
+        // per pair; with most correspondences inliers the cap falls below that at once) when the scoring
+        // launch can be split over correspondences with a moderate buffer, otherwise enough rows to fill
+        // the device.
         int64_t h = 256 * std::max<int64_t>(1, (2560 + n_pairs - 1) / n_pairs);
-        if (ctx->hyps_per_launch > 0) h = 256 * ((ctx->hyps_per_launch + 255) / 256); // caller's first slice
+        if (split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
+        if (ctx->hyps_per_launch > 0) h = 64 * ((ctx->hyps_per_launch + 63) / 64); // caller's first slice
         while (h < n_hyp) {
             bounds.push_back((int)h);
             h *= 4;
@@ -1188,13 +1300,27 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         if (rows > 0) hipLaunchKernelGGL(ransac_fit_kernel, dim3((rows + 63) / 64, n_pairs), dim3(64), 0, st, g);
         if (fit_only) continue;
         if (rows > 0) {
+            const size_t errBytes = (size_t)rows * (size_t)total * sizeof(double);
+            const int Z = split_factor(ctx, n_pairs, rows, total);
             SFM_HIP(ctx, sfm_span_begin(ctx, 1));
-            if (loss == SFM_LOSS_SAMPSON)
-                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON>), dim3((rows + 255) / 256, n_pairs), dim3(256),
-                                   0, st, g);
-            else
-                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION>), dim3((rows + 255) / 256, n_pairs),
-                                   dim3(256), 0, st, g);
+            const dim3 grid((rows + 255) / 256, n_pairs, Z);
+            if (Z > 1) {
+                SFM_HIP(ctx, b->errBuf.reserve(errBytes));
+                double *eb = b->errBuf.as<double>();
+                if (loss == SFM_LOSS_SAMPSON)
+                    hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON, true>), grid, dim3(256), 0, st, g, eb);
+                else
+                    hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION, true>), grid, dim3(256), 0, st, g, eb);
+                if ((int64_t)n_pairs * ((rows + 63) / 64) >= ctx->n_cus)
+                    hipLaunchKernelGGL(ransac_sum_kernel<64>, dim3((rows + 63) / 64, n_pairs), dim3(SUM_THREADS), 0, st, g, eb);
+                else
+                    hipLaunchKernelGGL(ransac_sum_kernel<16>, dim3((rows + 15) / 16, n_pairs), dim3(SUM_THREADS), 0, st, g, eb);
+            } else if (loss == SFM_LOSS_SAMPSON) {
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON, false>), grid, dim3(256), 0, st, g, (double *)nullptr);
+            } else {
+                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION, false>), grid, dim3(256), 0, st, g,
+                                   (double *)nullptr);
+            }
             SFM_HIP(ctx, sfm_span_end(ctx, 1));
         }
         hipLaunchKernelGGL(ransac_select_kernel, dim3(n_pairs), dim3(256), 0, st, g);
@@ -1353,6 +1479,15 @@ extern "C" int sfm_ransac_batch_inliers(sfm_ransac_batch *b, int32_t *inliers_ou
     return SFM_OK;
 }
 
+// The single-pair entry points keep their batch (device buffers) in the context between calls.
+static sfm_ransac_batch **pair_batch(sfm_ctx *ctx) { return &ctx->pair_batch; }
+
+void sfm_pair_batch_free(sfm_ctx *ctx)
+{
+    if (ctx->pair_batch) sfm_ransac_batch_destroy(ctx->pair_batch);
+    ctx->pair_batch = nullptr;
+}
+
 extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, int n, const double *K,
                                const int32_t *samples, int n_hyp, int min_n, double max_squared_error,
                                double success_prob, int adaptive, int loss, int32_t *inliers_out, int capacity,
@@ -1368,10 +1503,10 @@ extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, i
         SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "ransac: minN = %d has no kernel (the 8-point model needs exactly 8)", min_n);
     if (n < min_n) return SFM_OK; // RANSAC.cpp:148-149
     const int64_t off[2] = {0, n};
-    sfm_ransac_batch *b = nullptr;
     // every row is scored when the caller asks for the per-row outputs
     int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, max_squared_error, success_prob, adaptive, loss, false,
-                        false, &b, !counts_out && !toterr_out);
+                        false, pair_batch(ctx), !counts_out && !toterr_out);
+    sfm_ransac_batch *b = *pair_batch(ctx);
     int32_t bh = -1, bc = 0, it = 0;
     double be = 0, pose12[12];
     if (rc == SFM_OK) rc = sfm_ransac_batch_best(b, &bh, &bc, &be, pose12, &it);
@@ -1403,7 +1538,6 @@ extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, i
             rc = SFM_ERR_HIP;
         }
     }
-    sfm_ransac_batch_destroy(b);
     return rc;
 }
 
@@ -1416,8 +1550,9 @@ extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *
     if (n_hyp < 0 || (n_hyp > 0 && !pose12_out)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "fit: bad output");
     const int64_t off[2] = {0, n};
     const double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    sfm_ransac_batch *b = nullptr;
-    int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, true, &b);
+    int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, true,
+                        pair_batch(ctx));
+    sfm_ransac_batch *b = *pair_batch(ctx);
     if (rc == SFM_OK && n_hyp > 0) {
         hipError_t e = hipMemcpyAsync(pose12_out, b->pose12.p, (size_t)n_hyp * 12 * sizeof(double),
                                       hipMemcpyDeviceToHost, ctx->stream);
@@ -1427,7 +1562,6 @@ extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *
             rc = SFM_ERR_HIP;
         }
     }
-    sfm_ransac_batch_destroy(b);
     return rc;
 }
 
@@ -1441,11 +1575,11 @@ extern "C" int sfm_eight_point_algorithm(sfm_ctx *ctx, const double *x, const do
     if (!x || !y) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "EightPointAlgorithm: null input");
     const int64_t off[2] = {0, n};
     const double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    sfm_ransac_batch *b = nullptr;
     // no hypotheses: no inliers, so the refit takes every point
-    int rc = ransac_run(ctx, 1, off, x, y, K, nullptr, 0, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, false, &b);
+    int rc = ransac_run(ctx, 1, off, x, y, K, nullptr, 0, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, false,
+                        pair_batch(ctx));
+    sfm_ransac_batch *b = *pair_batch(ctx);
     if (rc == SFM_OK) rc = sfm_ransac_batch_refit(b);
     if (rc == SFM_OK) rc = sfm_ransac_batch_refit_fetch(b, pose16_out, nullptr, points_out);
-    sfm_ransac_batch_destroy(b);
     return rc;
 }

@@ -218,7 +218,7 @@ def test_pretest_is_off_for_unusual_intrinsics(ctx, oracle):
     assert_same_run(got, exp)
 
 
-@pytest.mark.parametrize("first_slice", [256, 1024])
+@pytest.mark.parametrize("first_slice", [64, 256, 1024])
 def test_sliced_adaptive_batch_equals_one_pass(ctx, oracle, first_slice):
     """With the adaptive cap on, a batch scores its sample rows in growing slices and pairs whose in-order
     scan has stopped skip the later slices.  Winner, inlier list, error sum and iteration count must be
@@ -251,3 +251,49 @@ def test_sliced_adaptive_batch_equals_one_pass(ctx, oracle, first_slice):
             assert best["toterr"][k] == e["toterr"][e["best_h"]], k
         stopped_early += e["iterations"] < first_slice
     assert stopped_early >= 2  # some pairs never see the later slices, others run all rows
+
+
+@pytest.mark.parametrize("loss", [capi.LOSS_REPROJECTION, capi.LOSS_SAMPSON])
+def test_split_scoring_is_bit_identical(ctx, oracle, loss):
+    """Small launches cut every pair's correspondences over several blocks and add the inliers' errors up
+    in a second kernel, in correspondence order: per-row counts and error sums must equal those of the
+    one-block-per-row-group path and of the restatement, bit for bit (RANSAC.cpp:207-221)."""
+    n, H = 3001, 700  # neither a multiple of the tile sizes
+    tv = synth.two_view(n, inlier_ratio=0.6, seed=77, noise_px=0.3)
+    S = synth.sample_table(n, H, seed=78)
+    kw = dict(max_sq_err=1.0, success_prob=0.999, loss=loss)
+    out = {}
+    for split in (1, 0):
+        ctx.set_option("ransac_split", split)
+        try:
+            out[split] = (ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, adaptive=False, **kw),
+                          ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, adaptive=True, per_row=False, **kw))
+        finally:
+            ctx.set_option("ransac_split", 1)
+    e = oracle.ransac(tv["x"], tv["y"], tv["K"], S, adaptive=False, loss_kind=loss, max_sq_err=kw["max_sq_err"],
+                      success_prob=0.999)
+    ea = oracle.ransac(tv["x"], tv["y"], tv["K"], S, adaptive=True, loss_kind=loss, max_sq_err=kw["max_sq_err"],
+                       success_prob=0.999)
+    assert e["counts"].max() > 100
+    for split in (1, 0):
+        full, adaptive = out[split]
+        assert np.array_equal(full["counts"], e["counts"]) and np.array_equal(full["toterr"], e["toterr"]), split
+        assert full["best_h"] == e["best_h"] and np.array_equal(full["inliers"], e["inliers"]), split
+        assert adaptive["best_h"] == ea["best_h"] and adaptive["iterations"] == ea["iterations"], split
+        assert np.array_equal(adaptive["inliers"], ea["inliers"]) and adaptive["counts"] is None, split
+
+
+def test_repeated_pair_calls_reuse_their_buffers(ctx, oracle):
+    """The single-pair entry points keep their device buffers in the context: a large call followed by
+    smaller and different ones must not see stale rows."""
+    for n, H, seed in [(1500, 512, 1), (40, 16, 2), (700, 2048, 3), (8, 1, 4)]:
+        tv = synth.two_view(n, inlier_ratio=0.5, seed=seed)
+        S = synth.sample_table(n, H, seed=seed + 10)
+        got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        e = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        it = e["iterations"]
+        assert got["best_h"] == e["best_h"] and np.array_equal(got["inliers"], e["inliers"])
+        assert np.array_equal(got["counts"][:it], e["counts"][:it]) and np.array_equal(got["toterr"][:it], e["toterr"][:it])
+        pose12 = ctx.eight_point_fit(tv["x"], tv["y"], S[:4])
+        ref12, _ = oracle.fit_hypotheses(tv["x"], tv["y"], S[:4])
+        assert np.array_equal(pose12, ref12)
