@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--images", type=int, default=200, help="images at N=1 (pairs per GPU = images*(images-1)/2)")
     ap.add_argument("--features", type=int, default=8192)
     ap.add_argument("--threshold", type=float, default=0.95)
+    ap.add_argument("--ratio", type=float, default=None,
+                    help="also apply Lowe's second-best ratio test (extension; not the reference's matcher)")
     ap.add_argument("--ransac-pairs", type=int, default=64)
     ap.add_argument("--ransac-corr", type=int, default=20000)
     ap.add_argument("--ransac-hyps", type=int, default=4096)
@@ -98,7 +100,8 @@ def main():
     res = None
 
     def launch(k):
-        results[k & 1] = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=results[k & 1])
+        results[k & 1] = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=results[k & 1],
+                                      ratio=args.ratio)
         return results[k & 1]
 
     def gather(r):
@@ -167,7 +170,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"synthetic {n_images} images x {args.features} x 128-d float SIFT-like descriptors, "
-                        f"exhaustive pairs ({total_pairs} pairs, {pairs_per_gpu}/GPU), threshold {args.threshold}",
+                        f"exhaustive pairs ({total_pairs} pairs, {pairs_per_gpu}/GPU), threshold {args.threshold}"
+                        + (f", second-best ratio test {args.ratio}" if args.ratio else ""),
             "images": n_images, "features_per_image": args.features, "dim": 128,
             "pairs_total": total_pairs, "pairs_per_gpu": pairs_per_gpu, "parallelism": f"pair-list dp{world}",
             "matches_rank0": int(total_matches), "candidates_rank0": int(cand), "overflow_rank0": int(ovf),

@@ -141,6 +141,18 @@ int sfm_match_batch(sfm_ctx *ctx, const sfm_imageset *set,
                     const int32_t *pair_list, int n_pairs,
                     int metric, float threshold, float max_distance_px_squared,
                     sfm_match_result **result_inout);
+/* Extension with no counterpart in the reference (its matcher has no second-best
+ * test; pinned by this library's CPU restatement only): sfm_match_batch with
+ * the cosine metric plus Lowe's ratio test on the unit sphere.  Row i whose
+ * best column j1 has similarity s1 keeps it only if every other column j
+ * inside the pixel gate has (1 - s1) < ratio^2 * (1 - sim(i, j)), evaluated in
+ * double on the fp32 similarities (d^2 = 2 - 2 sim, so this is d1 < ratio * d2
+ * for the second-nearest d2); rows that fail have no match, then the mutual
+ * check of match.cpp:84-91 runs as usual.  ratio in (0, 1]. */
+int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set,
+                          const int32_t *pair_list, int n_pairs,
+                          float threshold, float max_distance_px_squared, float ratio,
+                          sfm_match_result **result_inout);
 int sfm_match_result_total(sfm_match_result *res, int64_t *total_matches_out);
 int sfm_match_result_offsets(sfm_match_result *res, int64_t *offsets_out /* n_pairs+1 */);
 int sfm_match_result_pairs(sfm_match_result *res, int32_t *pairs_out /* 2*total */);

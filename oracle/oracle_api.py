@@ -45,6 +45,9 @@ def lib() -> C.CDLL:
     L.sfm_oracle_match.restype = C.c_int
     L.sfm_oracle_match.argtypes = [_f32p, _f64p, C.c_int, _f32p, _f64p, C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.c_float, _i32p, _i32p, _i32p]
+    L.sfm_oracle_match_ratio.restype = C.c_int
+    L.sfm_oracle_match_ratio.argtypes = [_f32p, _f64p, C.c_int, _f32p, _f64p, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, _i32p, _i32p, _i32p]
     L.sfm_oracle_eight_point_from_subset.restype = C.c_int
     L.sfm_oracle_eight_point_from_subset.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.c_int,
                                                      _f64p, _f64p, _i32p]
@@ -88,8 +91,9 @@ def similarity(a, b, metric=COSINE) -> float:
     return float(lib().sfm_oracle_similarity(a, b, a.size, metric))
 
 
-def match(descA, ptsA, descB, ptsB, threshold=0.5, max_dist_sq=1e8, metric=COSINE):
-    """matchTwoSided. Returns (pairs[k,2] int32, matches1[nA], matches2[nB])."""
+def match(descA, ptsA, descB, ptsB, threshold=0.5, max_dist_sq=1e8, metric=COSINE, ratio=None):
+    """matchTwoSided. Returns (pairs[k,2] int32, matches1[nA], matches2[nB]).  ratio: the extension with
+    Lowe's second-best test (cosine metric; no counterpart in the reference)."""
     descA = np.ascontiguousarray(descA, np.float32).reshape(len(ptsA), -1) if len(ptsA) else \
         np.zeros((0, np.asarray(descA).shape[-1] if np.asarray(descA).ndim == 2 else 128), np.float32)
     descB = np.ascontiguousarray(descB, np.float32).reshape(len(ptsB), -1) if len(ptsB) else \
@@ -102,10 +106,17 @@ def match(descA, ptsA, descB, ptsB, threshold=0.5, max_dist_sq=1e8, metric=COSIN
     m2 = np.full(max(nB, 1), -1, np.int32)
     pairs = np.zeros((max(min(nA, nB), 1), 2), np.int32)
     pad = lambda a, shape, dt: a if a.size else np.zeros(shape, dt)
-    cnt = lib().sfm_oracle_match(pad(descA, (1, dim), np.float32), pad(ptsA, (1, 2), np.float64), nA,
-                                 pad(descB, (1, dim), np.float32), pad(ptsB, (1, 2), np.float64), nB,
-                                 dim, metric, np.float32(threshold), np.float32(max_dist_sq),
-                                 m1, m2, pairs.reshape(-1))
+    if ratio is not None:
+        assert metric == COSINE
+        cnt = lib().sfm_oracle_match_ratio(pad(descA, (1, dim), np.float32), pad(ptsA, (1, 2), np.float64), nA,
+                                           pad(descB, (1, dim), np.float32), pad(ptsB, (1, 2), np.float64), nB,
+                                           dim, np.float32(threshold), np.float32(max_dist_sq), np.float32(ratio),
+                                           m1, m2, pairs.reshape(-1))
+    else:
+        cnt = lib().sfm_oracle_match(pad(descA, (1, dim), np.float32), pad(ptsA, (1, 2), np.float64), nA,
+                                     pad(descB, (1, dim), np.float32), pad(ptsB, (1, 2), np.float64), nB,
+                                     dim, metric, np.float32(threshold), np.float32(max_dist_sq),
+                                     m1, m2, pairs.reshape(-1))
     if cnt < 0:
         raise MemoryError("oracle similarity matrix allocation failed")
     return pairs[:cnt].copy(), m1[:nA].copy(), m2[:nB].copy()

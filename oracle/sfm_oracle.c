@@ -1092,3 +1092,65 @@ int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *t
     free(ratios);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Extension with no counterpart in the reference (PARITY UNPINNED by it): matchTwoSided
+ * (match.cpp:24-94) with Lowe's ratio test on the unit sphere between the two best-column scans.
+ * Row idx1 with best column j1 (similarity s1, as match.cpp:64-79 finds it) keeps it only if every
+ * other column j inside the pixel gate has (1 - s1) < ratio^2 (1 - sim(idx1, j)), in double on the
+ * float similarities; NaN similarities are ignored.  Rows that fail get matches1 = -1; the mutual
+ * check (match.cpp:84-91) follows.  Cosine metric.
+ * --------------------------------------------------------------------------------------------- */
+int sfm_oracle_match_ratio(const float *descA, const double *ptsA, int nA, const float *descB, const double *ptsB,
+                           int nB, int dim, float threshold, float maxDistancePxSquared, float ratio,
+                           int *matches1_out, int *matches2_out, int *pairs_out)
+{
+    int *m1 = (int *)malloc((size_t)(nA > 0 ? nA : 1) * sizeof(int));
+    int *m2 = (int *)malloc((size_t)(nB > 0 ? nB : 1) * sizeof(int));
+    if (!m1 || !m2) {
+        free(m1);
+        free(m2);
+        return -1;
+    }
+    int n = sfm_oracle_match(descA, ptsA, nA, descB, ptsB, nB, dim, 0, threshold, maxDistancePxSquared, m1, m2, NULL);
+    if (n < 0) {
+        free(m1);
+        free(m2);
+        return -1;
+    }
+    const double r2 = (double)ratio * (double)ratio;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nA; i++) {
+        const int j1 = m1[i];
+        if (j1 < 0) continue;
+        const float *a = descA + (size_t)i * dim;
+        const double s1 = (double)cosine_similarity(a, descB + (size_t)j1 * dim, (size_t)dim);
+        for (int j = 0; j < nB; j++) {
+            if (j == j1) continue;
+            const double dx = ptsA[2 * i] - ptsB[2 * j], dy = ptsA[2 * i + 1] - ptsB[2 * j + 1];
+            if (!(dx * dx + dy * dy < maxDistancePxSquared)) continue;
+            const float s = cosine_similarity(a, descB + (size_t)j * dim, (size_t)dim);
+            if (!(s == s)) continue;
+            if (!((1.0 - s1) < r2 * (1.0 - (double)s))) {
+                m1[i] = -1;
+                break;
+            }
+        }
+    }
+    int count = 0;
+    for (int i = 0; i < nA; i++) {
+        const int j = m1[i];
+        if (j != -1 && m2[j] == i) {
+            if (pairs_out) {
+                pairs_out[2 * count] = i;
+                pairs_out[2 * count + 1] = j;
+            }
+            count++;
+        }
+    }
+    if (matches1_out) memcpy(matches1_out, m1, (size_t)nA * sizeof(int));
+    if (matches2_out) memcpy(matches2_out, m2, (size_t)nB * sizeof(int));
+    free(m1);
+    free(m2);
+    return count;
+}

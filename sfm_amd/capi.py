@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
+    "sfm_match_batch_ratio",
 ]
 
 
@@ -77,6 +78,7 @@ def lib() -> C.CDLL:
     L.sfm_imageset_device_bytes.argtypes = [vp]
     L.sfm_imageset_device_bytes.restype = i64
     L.sfm_match_batch.argtypes = [vp, vp, vp, i32, i32, f32, f32, P(vp)]
+    L.sfm_match_batch_ratio.argtypes = [vp, vp, vp, i32, f32, f32, f32, P(vp)]
     L.sfm_match_result_total.argtypes = [vp, P(i64)]
     L.sfm_match_result_offsets.argtypes = [vp, vp]
     L.sfm_match_result_pairs.argtypes = [vp, vp]
@@ -342,11 +344,18 @@ class ImageSet:
         except Exception:
             pass
 
-    def match(self, pair_list, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE, result=None):
+    def match(self, pair_list, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE, result=None, ratio=None):
+        """ratio: Lowe's second-best test on top of the reference's matcher (sfm_match_batch_ratio)."""
         pl = np.ascontiguousarray(pair_list, np.int32).reshape(-1, 2)
         res = result if result is not None else MatchResult(self.ctx)
-        self.ctx.check(lib().sfm_match_batch(self.ctx._h, self._h, _ptr(pl), len(pl), metric, threshold,
-                                             max_dist_sq, C.byref(res._h)))
+        if ratio is not None:
+            if metric != METRIC_COSINE:
+                raise SfmError(ERR_UNSUPPORTED, "the second-best ratio test is defined for the cosine metric only")
+            self.ctx.check(lib().sfm_match_batch_ratio(self.ctx._h, self._h, _ptr(pl), len(pl), threshold,
+                                                       max_dist_sq, float(ratio), C.byref(res._h)))
+        else:
+            self.ctx.check(lib().sfm_match_batch(self.ctx._h, self._h, _ptr(pl), len(pl), metric, threshold,
+                                                 max_dist_sq, C.byref(res._h)))
         res.n_pairs = len(pl)
         return res
 

@@ -69,6 +69,8 @@ struct MatchArgs {
     int metric;
     float threshold;
     float maxDistSq;
+    double ratioSq;       // ratio mode (> 0): squared ratio of the second-best test
+    int *kill;            // ratio mode: [rows of the chunk, as best] 1 = the row's best fails the test
 };
 
 // ---------------------------------------------------------------------------------------
@@ -238,6 +240,35 @@ __device__ __forceinline__ void fold_cell(const MatchArgs &g, const PairRec &pr,
         for (int k = 0; k < g.dim; k++) dot = __fadd_rn(dot, __fmul_rn(a[k], b[k]));
     }
     fold_dot(g, pr, i, j, dot);
+}
+
+// Ratio mode, second sweep over the candidates (the row bests are final by then).  Row i with best
+// column j1 of similarity s1 keeps its match only if every other admissible column (inside the pixel
+// gate) stays clear of it on the unit sphere: with d^2 = 2 - 2 sim the test d1 < ratio * d2 reads
+// (1 - s1) < ratio^2 (1 - s2).  The condition falls with s2, so testing every column is testing the
+// second best.
+__device__ __forceinline__ void ratio_fold(const MatchArgs &g, const PairRec &pr, int i, int j, float dot)
+{
+    const u64 key = g.best[pr.bestRow + i];
+    if (key == 0) return;
+    if ((int)(0xFFFFFFFFu - (unsigned)key) == j) return;
+    const float sim = __fdiv_rn(dot, __fmul_rn(g.norms[pr.rowA32 + i], g.norms[pr.rowB32 + j]));
+    if (!(sim == sim)) return;
+    const double2 pa = g.pts[pr.rowA32 + i], pb = g.pts[pr.rowB32 + j];
+    const double dx = __dsub_rn(pa.x, pb.x), dy = __dsub_rn(pa.y, pb.y);
+    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+    if (!(d2 < (double)g.maxDistSq)) return;
+    const double s1 = (double)__uint_as_float((unsigned)(key >> 32));
+    if (!(__dsub_rn(1.0, s1) < __dmul_rn(g.ratioSq, __dsub_rn(1.0, (double)sim)))) g.kill[pr.bestRow + i] = 1;
+}
+
+__device__ __forceinline__ float exact_dot(const MatchArgs &g, const PairRec &pr, int i, int j)
+{
+    const float *a = g.desc32 + (size_t)(pr.rowA32 + i) * g.dim;
+    const float *b = g.desc32 + (size_t)(pr.rowB32 + j) * g.dim;
+    float dot = 0.0f;
+    for (int k = 0; k < g.dim; k++) dot = __fadd_rn(dot, __fmul_rn(a[k], b[k]));
+    return dot;
 }
 
 // Monotone map float -> unsigned (larger float, larger key); key 0 is below every float.
@@ -674,11 +705,14 @@ __device__ __forceinline__ int pair_queues(const MatchArgs &g, const PairRec &pr
     return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0;
 }
 
-// One wave per candidate slice, four slices per block.
-__global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
+// One wave per candidate slice, four slices per block.  RATIO: the second sweep of the ratio mode;
+// pairs that went through the filtered passes (their lists hold possible bests only) are left to
+// ratio_rows_kernel.
+template <bool RATIO> __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
 {
     const int p = blockIdx.y;
     if (g.pairOvf[p] == 2) return; // match_exact_kernel scores the whole pair
+    if (RATIO && g.pairOvf[p] == 1) return;
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= g.maxQueues) return;
@@ -687,11 +721,12 @@ __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
     if (q >= nQueues) return;
     const int cap = g.candCap / nQueues;
     const int n = g.candCount[p * g.maxQueues + q];
-    if (n > 0 && lane == 0) atomicAdd(&g.stats[0], (u64)n);
+    if (!RATIO && n > 0 && lane == 0) atomicAdd(&g.stats[0], (u64)n);
     const uint2 *list = g.cand + (size_t)p * g.candCap + (size_t)q * cap;
     for (int k = lane; k < n; k += 64) {
         const uint2 c = list[k];
-        fold_cell(g, pr, (int)c.x, (int)c.y);
+        if (RATIO) ratio_fold(g, pr, (int)c.x, (int)c.y, exact_dot(g, pr, (int)c.x, (int)c.y));
+        else fold_cell(g, pr, (int)c.x, (int)c.y);
     }
 }
 
@@ -701,7 +736,7 @@ __global__ __launch_bounds__(256) void match_cand_kernel(const MatchArgs g)
 // index order.  Candidates of a pair are numbered across its slices with a prefix sum so that
 // waves are full.
 #define CAND_ROWB 272 // LDS bytes per candidate per step: 2 x 128 B of data + 16 B pad (bank spread)
-template <bool U8> __global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
+template <bool U8, bool RATIO> __global__ __launch_bounds__(256) void match_cand128_kernel(const MatchArgs g)
 {
     __shared__ int prefix[1025];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][64 * CAND_ROWB];
@@ -709,6 +744,7 @@ template <bool U8> __global__ __launch_bounds__(256) void match_cand128_kernel(c
 
     const int p = blockIdx.y;
     if (g.pairOvf[p] == 2) return; // match_exact_kernel scores the whole pair
+    if (RATIO && g.pairOvf[p] == 1) return;
     const PairRec pr = g.pairs[p];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nQueues = pair_queues(g, pr, p);
@@ -731,7 +767,7 @@ template <bool U8> __global__ __launch_bounds__(256) void match_cand128_kernel(c
         __syncthreads();
     }
     const int total = prefix[nQueues];
-    if (blockIdx.x == 0 && tid == 0 && total > 0) atomicAdd(&g.stats[0], (u64)total);
+    if (!RATIO && blockIdx.x == 0 && tid == 0 && total > 0) atomicAdd(&g.stats[0], (u64)total);
 
     const float *A32 = g.desc32 + (size_t)pr.rowA32 * 128;
     const float *B32 = g.desc32 + (size_t)pr.rowB32 * 128;
@@ -819,8 +855,34 @@ template <bool U8> __global__ __launch_bounds__(256) void match_cand128_kernel(c
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (c < total) fold_dot(g, pr, (int)me.x, (int)me.y, dot);
+        if (c < total) {
+            if (RATIO) ratio_fold(g, pr, (int)me.x, (int)me.y, dot);
+            else fold_dot(g, pr, (int)me.x, (int)me.y, dot);
+        }
     }
+}
+
+// Ratio mode for the pairs whose lists do not hold every cell above the bound (filtered passes, or
+// scored cell by cell): every row that has a best walks all columns.  Rare and slow like
+// match_exact_kernel.  grid (blocks per pair, pairs of the chunk).
+__global__ __launch_bounds__(256) void ratio_rows_kernel(const MatchArgs g)
+{
+    const int p = blockIdx.y;
+    const int f = g.pairOvf[p];
+    if (f != 1 && f != 2) return;
+    const PairRec pr = g.pairs[p];
+    for (int i = blockIdx.x; i < pr.nA; i += gridDim.x) {
+        if (g.best[pr.bestRow + i] == 0) continue;
+        for (int j = threadIdx.x; j < pr.nB; j += 256) ratio_fold(g, pr, i, j, exact_dot(g, pr, i, j));
+    }
+}
+
+// Rows whose best failed the ratio test lose it (the mutual check then drops them).
+__global__ __launch_bounds__(256) void ratio_apply_kernel(const MatchArgs g)
+{
+    const PairRec pr = g.pairs[blockIdx.x];
+    for (int i = threadIdx.x; i < pr.nA; i += 256)
+        if (g.kill[pr.bestRow + i]) g.best[pr.bestRow + i] = 0;
 }
 
 // Pairs whose candidate list overflowed (one block): ovfList[0] = count, then the pair indices.
@@ -1133,7 +1195,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
-                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2};
+                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2, &r->kill};
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
@@ -1144,9 +1206,13 @@ int sfm_num_sim_variants() { return kNumSimVariants; }
 
 static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
                             int metric, float threshold, float maxDistSq, sfm_match_result **result_inout,
-                            bool want_m1m2)
+                            bool want_m1m2, float ratio = 0.0f)
 {
     if (!ctx || !set || !result_inout) return SFM_ERR_INVALID_ARG;
+    if (ratio != 0.0f && !(ratio > 0.0f && ratio <= 1.0f))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1], was %g", (double)ratio);
+    if (ratio != 0.0f && metric != SFM_METRIC_COSINE)
+        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "match: the second-best ratio test is defined for the cosine metric only");
     if (set->ctx != ctx) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: image set belongs to another context");
     if (n_pairs < 0 || (n_pairs > 0 && !pair_list)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: bad pair list");
     if (metric != SFM_METRIC_COSINE && metric != SFM_METRIC_DOT)
@@ -1239,7 +1305,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             r.chunkLocal = p - c0;
             const int wildMask = (metric == SFM_METRIC_COSINE) ? IMG_WILD_COS : IMG_WILD_DOT;
             const bool wild = ((set->flags[ia] | set->flags[ib]) & wildMask) != 0;
-            const float thrp = threshold > 0.0f ? threshold : 0.0f;
+            float thrp = threshold > 0.0f ? threshold : 0.0f;
+            // Ratio mode: a row whose best has similarity s1 > threshold is undone by any column at or
+            // above 1 - (1 - s1) / ratio^2, which is more than 1 - (1 - threshold) / ratio^2: the bound
+            // pass collects down to there, and the exact pass still applies the threshold itself.
+            if (ratio > 0.0f && threshold == threshold)
+                thrp = std::max(-2.0f, (float)(1.0 - (1.0 - (double)thrp) / ((double)ratio * ratio) - 1e-6));
             if (wild)
                 r.thr_m = -INFINITY;
             else if (metric == SFM_METRIC_COSINE)
@@ -1287,6 +1358,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->ovfList.reserve((size_t)(chunkPairs + 1) * sizeof(int)));
     SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
     SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
+    if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(int)));
     if (want_m1m2) {
         SFM_HIP(ctx, res->m1.reserve((size_t)(maxNA ? maxNA : 1) * sizeof(int32_t)));
         SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
@@ -1316,6 +1388,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.metric = metric;
     g.threshold = threshold;
     g.maxDistSq = maxDistSq;
+    g.ratioSq = (double)ratio * (double)ratio;
+    g.kill = ratio > 0.0f ? res->kill.as<int>() : nullptr;
 
     size_t ci = 0;
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
@@ -1367,15 +1441,28 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             g.onlyFlagged = 0;
             g.orient = 0;
             g.work = workList[0];
+            const bool fast128 = set->dim == 128 && maxQueues <= 1024;
             if (candCap > 0) {
-                if (set->dim == 128 && maxQueues <= 1024)
-                    hipLaunchKernelGGL(g.desc8u ? match_cand128_kernel<true> : match_cand128_kernel<false>, dim3(4, np),
-                                       dim3(256), 0, st, g);
+                if (fast128)
+                    hipLaunchKernelGGL((g.desc8u ? match_cand128_kernel<true, false> : match_cand128_kernel<false, false>),
+                                       dim3(4, np), dim3(256), 0, st, g);
                 else
-                    hipLaunchKernelGGL(match_cand_kernel, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
+                    hipLaunchKernelGGL(match_cand_kernel<false>, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
             }
             hipLaunchKernelGGL(match_overflow_list_kernel, dim3(1), dim3(256), 0, st, g, np);
             hipLaunchKernelGGL(match_exact_kernel, dim3(4 * ctx->n_cus), dim3(256), 0, st, g);
+            if (ratio > 0.0f) { // second sweep: rows whose second best comes too close lose their best
+                SFM_HIP(ctx, hipMemsetAsync(res->kill.p, 0, (size_t)bestLen * sizeof(int), st));
+                if (candCap > 0) {
+                    if (fast128)
+                        hipLaunchKernelGGL((g.desc8u ? match_cand128_kernel<true, true> : match_cand128_kernel<false, true>),
+                                           dim3(4, np), dim3(256), 0, st, g);
+                    else
+                        hipLaunchKernelGGL(match_cand_kernel<true>, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
+                }
+                hipLaunchKernelGGL(ratio_rows_kernel, dim3(64, np), dim3(256), 0, st, g);
+                hipLaunchKernelGGL(ratio_apply_kernel, dim3(np), dim3(256), 0, st, g);
+            }
         }
         hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
                            res->counts.as<int>(), (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr,
@@ -1396,6 +1483,16 @@ extern "C" int sfm_match_batch(sfm_ctx *ctx, const sfm_imageset *set, const int3
 {
     return match_batch_impl(ctx, set, pair_list, n_pairs, metric, threshold, max_distance_px_squared,
                             result_inout, false);
+}
+
+extern "C" int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
+                                     float threshold, float max_distance_px_squared, float ratio,
+                                     sfm_match_result **result_inout)
+{
+    if (ctx && !(ratio > 0.0f && ratio <= 1.0f))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1], was %g", (double)ratio);
+    return match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_COSINE, threshold, max_distance_px_squared,
+                            result_inout, false, ratio);
 }
 
 extern "C" int sfm_match_result_total(sfm_match_result *res, int64_t *total_out)

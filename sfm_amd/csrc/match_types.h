@@ -41,7 +41,7 @@ struct sfm_match_result {
     int n_pairs = 0;
     DevBuf offsets; // int64[n_pairs+1]
     DevBuf pairs;   // int2[sum min(nA,nB)]
-    DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2;
+    DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2, kill;
     PinBuf hostRecs, hostWork;
     int64_t total = -1;
 };

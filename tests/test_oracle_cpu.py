@@ -296,3 +296,26 @@ def test_scale_chain_median_is_upper(oracle):
     poses = np.stack([np.eye(4)] * 2)  # |pose12 * P12| = P12's depth
     got = oracle.scale_chain(off, np.concatenate([ids, ids]), np.concatenate([p12, p23]), poses, n_tracks=6)
     assert got["scale"][0] == 1.0 and got["scale"][1] == 4.0
+
+
+# ---- second-best ratio test (extension) -----------------------------------------------------------
+def test_match_ratio_by_hand(oracle):
+    """Unit vectors in the plane, similarity = cos of the angle between them.  Row 0 sees columns at
+    10 and 25 degrees, row 1 one column only, row 2 two columns at 5 and 6 degrees."""
+    def unit(deg):
+        r = np.radians(deg)
+        return [np.cos(r), np.sin(r)]
+    A = np.array([unit(0), unit(90), unit(200)], np.float32)
+    B = np.array([unit(10), unit(25), unit(92), unit(205), unit(206)], np.float32)
+    pA, pB = np.zeros((3, 2)), np.zeros((5, 2))
+    plain, m1, _ = oracle.match(A, pA, B, pB, threshold=0.5, max_dist_sq=1.0)
+    assert plain.tolist() == [[0, 0], [1, 2], [2, 3]]
+    # d^2 = 2 - 2 cos: row 0 d1/d2 = sin(5)/sin(12.5) = 0.403, row 2 sin(2.5)/sin(3) = 0.833
+    for ratio, want in ((0.9, [[0, 0], [1, 2], [2, 3]]), (0.8, [[0, 0], [1, 2]]), (0.4, [[1, 2]])):
+        got, _, _ = oracle.match(A, pA, B, pB, threshold=0.5, max_dist_sq=1.0, ratio=ratio)
+        assert got.tolist() == want, ratio
+    # the pixel gate hides the rival of row 2
+    pB2 = pB.copy()
+    pB2[4] = [100, 0]
+    got, _, _ = oracle.match(A, pA, B, pB2, threshold=0.5, max_dist_sq=1.0, ratio=0.8)
+    assert got.tolist() == [[0, 0], [1, 2], [2, 3]]
