@@ -75,7 +75,9 @@ const char *sfm_version(void);
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
  * everything; results are identical), "chain_table_entries" (entries of the
  * scale chain's (step, track) table, default 2^26; a sequence that needs more
- * goes through in windows of steps; results are identical).
+ * goes through in windows of steps; results are identical), "hamming_mfma"
+ * (1 = 256-bit binary descriptors are first matched on the matrix cores as
+ * sign vectors, default; 0 = popcount kernel only; results are identical).
  * Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */
 int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);
@@ -239,6 +241,24 @@ int sfm_ransac_batch_refit(sfm_ransac_batch *b);
 int sfm_ransac_batch_refit_fetch(sfm_ransac_batch *b, double *pose16_out, int32_t *used_out,
                                  double *points_out);
 void sfm_ransac_batch_destroy(sfm_ransac_batch *b);
+
+/* ---- binary descriptors (extension) -----------------------------------------
+ * No counterpart in the reference (its descriptors are float vectors,
+ * SfM.hpp:132); pinned by this library's CPU restatement only.  The structure
+ * of matchTwoSided (match.cpp:24-94) under the Hamming distance: a cell is
+ * admissible when popcount(a xor b) <= max_distance and the keypoints lie
+ * inside the pixel gate; rows and columns take their nearest admissible cell,
+ * the lowest index among equals; mutual pairs, ascending row.
+ * desc[sum(counts)][bytes_per_desc] uint8 (16, 32 or 64 bytes: 128, 256 or 512
+ * bits), pts[sum(counts)][2] pixels.  The result is an ordinary match result.
+ */
+typedef struct sfm_binset sfm_binset;
+int sfm_binset_create(sfm_ctx *ctx, int n_images, const int32_t *counts, const uint8_t *desc,
+                      const double *pts, int bytes_per_desc, sfm_binset **set_out);
+void sfm_binset_destroy(sfm_binset *set);
+int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, const int32_t *pair_list, int n_pairs,
+                            int max_distance, float max_distance_px_squared,
+                            sfm_match_result **result_inout);
 
 /* ---- matching -> RANSAC without leaving the device -------------------------
  * Replaces the correspondence assembly of Scene::getApproximations,

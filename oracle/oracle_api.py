@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libsfm_oracle.so")
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 
 
@@ -48,6 +49,9 @@ def lib() -> C.CDLL:
     L.sfm_oracle_match_ratio.restype = C.c_int
     L.sfm_oracle_match_ratio.argtypes = [_f32p, _f64p, C.c_int, _f32p, _f64p, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, _i32p, _i32p, _i32p]
+    L.sfm_oracle_match_hamming.restype = C.c_int
+    L.sfm_oracle_match_hamming.argtypes = [_u8p, _f64p, C.c_int, _u8p, _f64p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           _i32p, _i32p, _i32p]
     L.sfm_oracle_eight_point_from_subset.restype = C.c_int
     L.sfm_oracle_eight_point_from_subset.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.c_int,
                                                      _f64p, _f64p, _i32p]
@@ -254,3 +258,24 @@ def scale_chain(offsets, track_ids, points, poses, start_pose=None, max_translat
         raise MemoryError("scale chain")
     return dict(extrinsics=extr.reshape(S + 1, 4, 4).transpose(0, 2, 1).copy(), points3d=pts[:n_tracks],
                 counts=cnt[:n_tracks], scale=scale[:S])
+
+
+def match_hamming(descA, ptsA, descB, ptsB, max_distance=64, max_dist_sq=1e8):
+    """Mutual nearest neighbours of binary descriptors (uint8 [n, bytes]) under the Hamming distance.
+    Returns (pairs[k,2] int32, matches1[nA], matches2[nB])."""
+    descA = np.ascontiguousarray(descA, np.uint8)
+    descB = np.ascontiguousarray(descB, np.uint8)
+    nbytes = descA.shape[1] if descA.ndim == 2 and descA.shape[0] else descB.shape[1]
+    ptsA = np.ascontiguousarray(ptsA, np.float64).reshape(-1, 2)
+    ptsB = np.ascontiguousarray(ptsB, np.float64).reshape(-1, 2)
+    nA, nB = len(ptsA), len(ptsB)
+    m1 = np.full(max(nA, 1), -1, np.int32)
+    m2 = np.full(max(nB, 1), -1, np.int32)
+    pairs = np.zeros((max(min(nA, nB), 1), 2), np.int32)
+    pad = lambda a, shape, dt: a if a.size else np.zeros(shape, dt)
+    cnt = lib().sfm_oracle_match_hamming(pad(descA, (1, nbytes), np.uint8), pad(ptsA, (1, 2), np.float64), nA,
+                                         pad(descB, (1, nbytes), np.uint8), pad(ptsB, (1, 2), np.float64), nB,
+                                         nbytes, int(max_distance), np.float32(max_dist_sq), m1, m2, pairs.reshape(-1))
+    if cnt < 0:
+        raise MemoryError("oracle allocation failed")
+    return pairs[:cnt].copy(), m1[:nA].copy(), m2[:nB].copy()

@@ -1154,3 +1154,65 @@ int sfm_oracle_match_ratio(const float *descA, const double *ptsA, int nA, const
     free(m2);
     return count;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Extension with no counterpart in the reference (PARITY UNPINNED by it; the reference has float
+ * descriptors only, SfM.hpp:132): the structure of matchTwoSided (match.cpp:24-94) on binary
+ * descriptors under the Hamming distance.  A cell is admissible when popcount(a xor b) <=
+ * max_distance and the keypoints are inside the pixel gate; every column takes its nearest admissible
+ * row and every row its nearest admissible column, the first of equals (the strict scans of
+ * match.cpp:49,72); mutual pairs in ascending row order (match.cpp:84-91).
+ * --------------------------------------------------------------------------------------------- */
+int sfm_oracle_match_hamming(const uint8_t *descA, const double *ptsA, int nA, const uint8_t *descB, const double *ptsB,
+                             int nB, int bytes, int max_distance, float maxDistancePxSquared, int *matches1_out,
+                             int *matches2_out, int *pairs_out)
+{
+    int *m1 = (int *)malloc((size_t)(nA > 0 ? nA : 1) * sizeof(int));
+    int *m2 = (int *)malloc((size_t)(nB > 0 ? nB : 1) * sizeof(int));
+    int *d2 = (int *)malloc((size_t)(nB > 0 ? nB : 1) * sizeof(int));
+    if (!m1 || !m2 || !d2) {
+        free(m1);
+        free(m2);
+        free(d2);
+        return -1;
+    }
+    for (int j = 0; j < nB; j++) {
+        m2[j] = -1;
+        d2[j] = 0x7FFFFFFF;
+    }
+    for (int i = 0; i < nA; i++) {
+        int best = 0x7FFFFFFF, bestJ = -1;
+        for (int j = 0; j < nB; j++) {
+            int d = 0;
+            for (int k = 0; k < bytes; k++) d += __builtin_popcount((unsigned)(descA[(size_t)i * bytes + k] ^ descB[(size_t)j * bytes + k]));
+            const double dx = ptsA[2 * i] - ptsB[2 * j], dy = ptsA[2 * i + 1] - ptsB[2 * j + 1];
+            if (d > max_distance || !(dx * dx + dy * dy < maxDistancePxSquared)) continue;
+            if (d < best) {
+                best = d;
+                bestJ = j;
+            }
+            if (d < d2[j]) { /* rows come in ascending order: the first of equals stays */
+                d2[j] = d;
+                m2[j] = i;
+            }
+        }
+        m1[i] = bestJ;
+    }
+    int count = 0;
+    for (int i = 0; i < nA; i++) {
+        const int j = m1[i];
+        if (j != -1 && m2[j] == i) {
+            if (pairs_out) {
+                pairs_out[2 * count] = i;
+                pairs_out[2 * count + 1] = j;
+            }
+            count++;
+        }
+    }
+    if (matches1_out) memcpy(matches1_out, m1, (size_t)nA * sizeof(int));
+    if (matches2_out) memcpy(matches2_out, m2, (size_t)nB * sizeof(int));
+    free(m1);
+    free(m2);
+    free(d2);
+    return count;
+}

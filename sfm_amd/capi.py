@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
-    "sfm_match_batch_ratio",
+    "sfm_match_batch_ratio", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
 ]
 
 
@@ -79,6 +79,10 @@ def lib() -> C.CDLL:
     L.sfm_imageset_device_bytes.restype = i64
     L.sfm_match_batch.argtypes = [vp, vp, vp, i32, i32, f32, f32, P(vp)]
     L.sfm_match_batch_ratio.argtypes = [vp, vp, vp, i32, f32, f32, f32, P(vp)]
+    L.sfm_binset_create.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
+    L.sfm_binset_destroy.argtypes = [vp]
+    L.sfm_binset_destroy.restype = None
+    L.sfm_match_batch_hamming.argtypes = [vp, vp, vp, i32, i32, f32, P(vp)]
     L.sfm_match_result_total.argtypes = [vp, P(i64)]
     L.sfm_match_result_offsets.argtypes = [vp, vp]
     L.sfm_match_result_pairs.argtypes = [vp, vp]
@@ -358,6 +362,40 @@ class ImageSet:
                                                  max_dist_sq, C.byref(res._h)))
         res.n_pairs = len(pl)
         return res
+
+
+class BinarySet:
+    """Binary descriptor table resident in HBM (sfm_binset_*): uint8 [rows, 16 | 32 | 64]."""
+
+    def __init__(self, ctx: Context, counts, desc, pts):
+        _live.add(self)
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        counts = np.ascontiguousarray(counts, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        nbytes = desc.shape[1] if desc.ndim == 2 else 32
+        ctx.check(lib().sfm_binset_create(ctx._h, len(counts), _ptr(counts), _ptr(desc), _ptr(pts), nbytes,
+                                          C.byref(self._h)))
+
+    def match(self, pair_list, max_distance=64, max_dist_sq=1e8, result=None):
+        pl = np.ascontiguousarray(pair_list, np.int32).reshape(-1, 2)
+        res = result if result is not None else MatchResult(self.ctx)
+        self.ctx.check(lib().sfm_match_batch_hamming(self.ctx._h, self._h, _ptr(pl), len(pl), int(max_distance),
+                                                     max_dist_sq, C.byref(res._h)))
+        res.n_pairs = len(pl)
+        return res
+
+    def close(self):
+        if self._h:
+            lib().sfm_binset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MatchResult:

@@ -21,6 +21,7 @@ struct sfm_ctx {
     int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
     int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
+    int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };

@@ -70,6 +70,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "chain_table_entries")) {
         if (value < 2) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "chain_table_entries must be >= 2");
         ctx->chain_table_entries = value;
+    } else if (!strcmp(key, "hamming_mfma")) {
+        ctx->hamming_mfma = value != 0;
     } else if (!strcmp(key, "ransac_split")) {
         ctx->ransac_split = value != 0;
     } else if (!strcmp(key, "ransac_filter")) {

@@ -44,34 +44,6 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 #define IMG_WILD_DOT 2 // a descriptor norm that is 0, non-finite or outside that range
 #define IMG_NOT_U8 4   // an element that is not an integer in [0, 255]
 
-struct MatchArgs {
-    const _Float16 *desc16;
-    const signed char *desc8; // unit-normalised descriptors quantised to int8, 128 bytes per row
-    const unsigned char *desc8u; // byte copy of desc32 (dim 128, rows as desc32) when every element is an integer in [0, 255], else null
-    const float *desc32;
-    const float *norms;
-    const double2 *pts;
-    const PairRec *pairs; // chunk base
-    const int2 *work;     // (pair in chunk, row block), -1 = no work
-    uint2 *cand;          // [pairs in chunk][candCap]
-    int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
-    int *pairOvf;         // [pairs in chunk]: a slice overflowed in 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
-    int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
-    int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
-    int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
-    u64 *best;            // row keys and column keys of the chunk
-    int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
-    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell, [2] pairs that needed the filtered passes, [3] pairs settled by the fp16 strict pass after the int8 one flooded
-    int candCap;
-    int blockRows;        // rows of image A per block of the similarity kernel instance in use
-    int wavesPerBlock;
-    int dim;
-    int metric;
-    float threshold;
-    float maxDistSq;
-    double ratioSq;       // ratio mode (> 0): squared ratio of the second-best test
-    int *kill;            // ratio mode: [rows of the chunk, as best] 1 = the row's best fails the test
-};
 
 // ---------------------------------------------------------------------------------------
 // ingest
@@ -511,13 +483,16 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // conflict-free is applied to the per-lane source address:
 //   fp16: 16-B chunk c of row r sits at chunk c ^ (r & 15) of its 256-B LDS line;
 //   int8: a 256-B LDS line holds rows 2L and 2L + 1; chunk c of row 2L + b sits at (8b + c) ^ (L & 15).
-// OCC = blocks per CU the register budget is set for.  I8 selects the int8 form (strict cosine only).
+// OCC = blocks per CU the register budget is set for.  FORM selects the arithmetic (the int8 forms have strict instances only).
 // ABL: timing-only ablations with wrong results: bit 0 = no staging and no barrier, bit 1 = no
 // candidate test.
-template <int OCC, bool I8, bool DOT, bool GENERAL, int ABL>
+template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
 __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
 {
-    constexpr int ROWB = I8 ? 128 : 256;                   // bytes per descriptor row in the table and in LDS
+    // FORM 0: fp16 rows of 256 B; 1: int8 rows of 128 B; 2: int8 rows of 256 B (256 signs of a binary descriptor)
+    constexpr bool I8 = FORM != 0;       // int8 MFMA, int32 sums
+    constexpr bool WIDE = FORM != 1;     // 256-byte rows: the fp16 table's layout in memory and in LDS
+    constexpr int ROWB = WIDE ? 256 : 128;                   // bytes per descriptor row in the table and in LDS
     constexpr int DMA = SIM_BN * ROWB / 1024 / SIM_WAVES;  // LDS-DMA instructions per wave per step
     static_assert(SIM_BN * ROWB % (1024 * SIM_WAVES) == 0 && SIM_BN == 64, "step must split evenly");
     static_assert(!I8 || (!GENERAL && !DOT), "the int8 bound has a strict cosine instance only");
@@ -551,7 +526,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     const unsigned char *Brows = table + (size_t)pr.rowB16 * ROWB;
 
     // A fragments: row tile t (16 rows), k-block s; fp16 has four k-blocks of 32, int8 two of 64.
-    constexpr int NKB = I8 ? 2 : 4;
+    constexpr int NKB = WIDE ? 4 : 2;
     typedef typename std::conditional<I8, int4v, half8>::type Frag; // 16 bytes either way
     Frag a[4][NKB];
 #pragma unroll
@@ -573,7 +548,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     for (int u = 0; u < DMA; u++) {
         const int line = 4 * (wave * DMA + u) + (lane >> 4);
         const int logical = (lane & 15) ^ (line & 15);
-        srcOff[u] = I8 ? (2 * line + (logical >> 3)) * 128 + ((logical & 7) << 4) : line * 256 + (logical << 4);
+        srcOff[u] = !WIDE ? (2 * line + (logical >> 3)) * 128 + ((logical & 7) << 4) : line * 256 + (logical << 4);
     }
     auto dma_issue = [&](int c, int buf) __attribute__((always_inline)) {
         const unsigned char *src = Brows + (size_t)c * SIM_BN * ROWB;
@@ -603,7 +578,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
             for (int s = 0; s < NKB; s++) {
                 const int row = sub * 32 + ct * 16 + (lane & 15);
                 const int chunk = s * 4 + (lane >> 4);
-                const int at = I8 ? (row >> 1) * 256 + ((((row & 1) * 8 + chunk) ^ ((row >> 1) & 15)) << 4)
+                const int at = !WIDE ? (row >> 1) * 256 + ((((row & 1) * 8 + chunk) ^ ((row >> 1) & 15)) << 4)
                                   : row * 256 + ((chunk ^ (row & 15)) << 4);
                 const Frag b = *reinterpret_cast<const Frag *>(&lds[buf][at]);
 #pragma unroll
@@ -689,6 +664,12 @@ static const SimVariant kSimVariants[] = {
     {match_sim_kernel<5, true, false, false, 3>, nullptr, "int8, neither staging nor test (timing only)"},      // 5
 };
 // cosine with the row-best filter (loose thresholds), and the dot metric: fp16 bound, two blocks per CU
+// Binary descriptors as 256 signs (+1 / -1) per row: the int32 sum is 256 - 2 * Hamming distance, exactly.
+void sfm_launch_sim_signs(const MatchArgs &g, int blocks, hipStream_t st)
+{
+    hipLaunchKernelGGL((match_sim_kernel<4, 2, false, false, 0>), dim3(blocks), dim3(SIM_WAVES * 64), 0, st, g);
+}
+
 static void (*const kSimGeneral)(const MatchArgs) = match_sim_kernel<2, false, false, true, 0>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
@@ -922,87 +903,7 @@ __global__ __launch_bounds__(256) void match_exact_kernel(const MatchArgs g)
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// mutual check + ordered compaction (match.cpp:84-91)
-// ---------------------------------------------------------------------------------------
-// One block per pair.  WRITE = false counts, WRITE = true writes (i, j) at offsets[p].
-template <bool WRITE>
-__global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__restrict__ pairs,
-                                                           const u64 *__restrict__ best,
-                                                           int *__restrict__ counts,
-                                                           const int64_t *__restrict__ offsets,
-                                                           int2 *__restrict__ out,
-                                                           int32_t *__restrict__ m1out,
-                                                           int32_t *__restrict__ m2out)
-{
-    __shared__ int waveCnt[4];
-    const int p = blockIdx.x;
-    const PairRec pr = pairs[p];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 *rowKey = best + pr.bestRow;
-    const u64 *colKey = best + pr.bestCol;
-    int2 *dst = WRITE ? out + offsets[p] : nullptr;
-    int running = 0;
-    for (int base = 0; base < pr.nA; base += 256) {
-        const int i = base + tid;
-        bool ok = false;
-        int j = -1;
-        if (i < pr.nA) {
-            const u64 kr = rowKey[i];
-            if (kr != 0) {
-                j = (int)(0xFFFFFFFFu - (unsigned)kr);
-                const u64 kc = colKey[j];
-                ok = kc != 0 && (int)(0xFFFFFFFFu - (unsigned)kc) == i;
-            }
-            if (WRITE && m1out) m1out[i] = j;
-        }
-        const u64 mask = __builtin_amdgcn_ballot_w64(ok);
-        const int prefix = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
-        __syncthreads();
-        int off = running, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k < wave) off += waveCnt[k];
-            tot += waveCnt[k];
-        }
-        if (WRITE && ok) dst[off + prefix] = make_int2(i, j);
-        running += tot;
-        __syncthreads();
-    }
-    if (!WRITE && tid == 0) counts[p] = running;
-    if (WRITE && m2out) {
-        for (int j = tid; j < pr.nB; j += 256) {
-            const u64 kc = colKey[j];
-            m2out[j] = kc ? (int)(0xFFFFFFFFu - (unsigned)kc) : -1;
-        }
-    }
-}
-
-// offsets[first + k + 1] = offsets[first] + sum(counts[0..k]); one block.
-__global__ __launch_bounds__(1024) void match_scan_kernel(const int *__restrict__ counts, int n,
-                                                          int64_t *__restrict__ offsets, int64_t first)
-{
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = tid * per, hi = min(n, lo + per);
-    int64_t s = 0;
-    for (int k = lo; k < hi; k++) s += counts[k];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int64_t v = (tid >= d) ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int64_t run = offsets[first] + (tid ? part[tid - 1] : 0);
-    for (int k = lo; k < hi; k++) {
-        run += counts[k];
-        offsets[first + k + 1] = run;
-    }
-}
+#include "csr_kernels.h"
 
 // ---------------------------------------------------------------------------------------
 // host side

@@ -22,6 +22,41 @@ struct ImageRec {
     int64_t row16;
 };
 
+typedef unsigned long long u64;
+
+struct MatchArgs {
+    const _Float16 *desc16;
+    const signed char *desc8; // unit-normalised descriptors quantised to int8, 128 bytes per row
+    const unsigned char *desc8u; // byte copy of desc32 (dim 128, rows as desc32) when every element is an integer in [0, 255], else null
+    const float *desc32;
+    const float *norms;
+    const double2 *pts;
+    const PairRec *pairs; // chunk base
+    const int2 *work;     // (pair in chunk, row block), -1 = no work
+    uint2 *cand;          // [pairs in chunk][candCap]
+    int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
+    int *pairOvf;         // [pairs in chunk]: a slice overflowed in 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
+    int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
+    int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
+    int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
+    u64 *best;            // row keys and column keys of the chunk
+    int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
+    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell, [2] pairs that needed the filtered passes, [3] pairs settled by the fp16 strict pass after the int8 one flooded
+    int candCap;
+    int blockRows;        // rows of image A per block of the similarity kernel instance in use
+    int wavesPerBlock;
+    int dim;
+    int metric;
+    float threshold;
+    float maxDistSq;
+    double ratioSq;       // ratio mode (> 0): squared ratio of the second-best test
+    int *kill;            // ratio mode: [rows of the chunk, as best] 1 = the row's best fails the test
+};
+
+// Strict similarity pass over a table of 256 signs per row (g.desc8, rows of 256 B); candidates are the
+// cells whose int32 sum exceeds PairRec::thr_i.  Defined beside the similarity kernel.
+void sfm_launch_sim_signs(const MatchArgs &g, int blocks, hipStream_t st);
+
 struct sfm_imageset {
     sfm_ctx *ctx = nullptr;
     int n_images = 0;

@@ -319,3 +319,23 @@ def test_match_ratio_by_hand(oracle):
     pB2[4] = [100, 0]
     got, _, _ = oracle.match(A, pA, B, pB2, threshold=0.5, max_dist_sq=1.0, ratio=0.8)
     assert got.tolist() == [[0, 0], [1, 2], [2, 3]]
+
+
+# ---- binary descriptors (extension) ---------------------------------------------------------------
+def test_match_hamming_by_hand(oracle):
+    def bits(*ones):
+        v = np.zeros(128, np.uint8)
+        v[list(ones)] = 1
+        return np.packbits(v)
+    A = np.array([bits(0, 1, 2), bits(50), bits(100, 101)])
+    B = np.array([bits(0, 1), bits(0, 1, 2, 3), bits(50, 51, 52), bits(100, 101), bits(100, 101)])
+    pA, pB = np.zeros((3, 2)), np.zeros((5, 2))
+    # distances: row 0 -> (1, 1, ...): the first of equals, column 0; row 1 -> column 2 at 2; row 2 -> 3 and 4 at 0
+    pairs, m1, m2 = oracle.match_hamming(A, pA, B, pB, max_distance=2, max_dist_sq=1.0)
+    assert m1.tolist() == [0, 2, 3] and m2.tolist() == [0, 0, 1, 2, 2]
+    assert pairs.tolist() == [[0, 0], [1, 2], [2, 3]]
+    pairs, _, _ = oracle.match_hamming(A, pA, B, pB, max_distance=1, max_dist_sq=1.0)
+    assert pairs.tolist() == [[0, 0], [2, 3]]
+    pB[3] = [10, 0]  # the gate hides column 3: row 2 falls back to its twin
+    pairs, _, _ = oracle.match_hamming(A, pA, B, pB, max_distance=2, max_dist_sq=1.0)
+    assert pairs.tolist() == [[0, 0], [1, 2], [2, 4]]
