@@ -31,10 +31,13 @@ struct sfm_ctx {
     // scale chain: work space kept between calls, and the size of its (step, track) table
     struct ChainScratch *chain = nullptr;
     sfm_ransac_batch *pair_batch = nullptr; // device buffers of the single-pair RANSAC entry points
+    sfm_imageset *pair_set = nullptr;       // and of the single-pair matcher
+    sfm_match_result *pair_result = nullptr;
     int64_t chain_table_entries = (int64_t)1 << 26;
 };
 void sfm_chain_scratch_free(sfm_ctx *ctx);
 void sfm_pair_batch_free(sfm_ctx *ctx);
+void sfm_pair_match_free(sfm_ctx *ctx);
 
 #define SFM_FAIL(ctx, code, ...)                                   \
     do {                                                           \

@@ -37,6 +37,7 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sfm_chain_scratch_free(ctx);
     sfm_pair_batch_free(ctx);
+    sfm_pair_match_free(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int w = 0; w < 2; w++)
         for (auto &s : ctx->span_pool[w]) {

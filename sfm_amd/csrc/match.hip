@@ -931,9 +931,20 @@ extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
     return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->desc8u.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
 }
 
+// Two host tables that together form the set's table (image 0 then image 1): the single-pair entry
+// point uploads its two operands without first copying them side by side.
+struct TwoParts {
+    const float *desc[2];
+    const double *pts[2];
+};
+
+// reuse: slot holding a set built earlier by this function from host tables, whose device buffers are
+// kept (they only grow).  The slot is emptied when the set is taken; on failure the set is destroyed like
+// a new one, on success the caller puts the result back.
 static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, const float *desc,
                           const double *pts, int dim, bool on_device, sfm_imageset **set_out,
-                          const unsigned char *desc_bytes = nullptr)
+                          const unsigned char *desc_bytes = nullptr, sfm_imageset **reuse = nullptr,
+                          const TwoParts *parts = nullptr)
 {
     if (!ctx || !set_out) return SFM_ERR_INVALID_ARG;
     *set_out = nullptr;
@@ -944,9 +955,12 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     if (n_images > 65535) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "imageset: more than 65535 images");
     SFM_HIP(ctx, hipSetDevice(ctx->device));
 
-    sfm_imageset *s = new (std::nothrow) sfm_imageset();
+    sfm_imageset *s = (reuse && *reuse) ? *reuse : new (std::nothrow) sfm_imageset();
     if (!s) SFM_FAIL(ctx, SFM_ERR_OOM, "imageset: host allocation failed");
+    if (reuse) *reuse = nullptr;
     s->ctx = ctx;
+    s->scale8.clear();
+    s->l1max.clear();
     s->n_images = n_images;
     s->dim = dim;
     s->images.resize(n_images);
@@ -954,7 +968,7 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     int64_t r32 = 0, r16 = 0;
     for (int i = 0; i < n_images; i++) {
         if (counts[i] < 0) {
-            delete s;
+            sfm_imageset_destroy(s);
             SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: counts[%d] < 0", i);
         }
         s->images[i] = ImageRec{counts[i], 0, r32, r16};
@@ -966,8 +980,8 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     // one extra padded block so that a B tile or an A block may read past the last image
     r16 += ROW_PAD;
     s->rows16 = r16;
-    if (r32 > 0 && ((!desc && !desc_bytes) || !pts)) {
-        delete s;
+    if (r32 > 0 && !parts && ((!desc && !desc_bytes) || !pts)) {
+        sfm_imageset_destroy(s);
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "imageset: null descriptor or point table");
     }
 
@@ -1000,9 +1014,21 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
                                (const unsigned char *)tmp.p, n, s->desc32.as<float>());
             SET_HIP(hipStreamSynchronize(ctx->stream));
             tmp.release();
+        } else if (parts) {
+            int64_t row = 0;
+            for (int k = 0; k < 2 && k < n_images; k++) {
+                const size_t nk = (size_t)counts[k];
+                if (nk) {
+                    SET_HIP(hipMemcpyAsync(s->desc32.as<float>() + (size_t)row * dim, parts->desc[k], nk * dim * sizeof(float),
+                                           hipMemcpyHostToDevice, ctx->stream));
+                    SET_HIP(hipMemcpyAsync(s->pts.as<double>() + (size_t)row * 2, parts->pts[k], nk * 2 * sizeof(double),
+                                           hipMemcpyHostToDevice, ctx->stream));
+                }
+                row += counts[k];
+            }
         } else if (b32)
             SET_HIP(hipMemcpyAsync(s->desc32.p, desc, b32, hipMemcpyHostToDevice, ctx->stream));
-        if (bpts) SET_HIP(hipMemcpyAsync(s->pts.p, pts, bpts, hipMemcpyHostToDevice, ctx->stream));
+        if (bpts && !parts) SET_HIP(hipMemcpyAsync(s->pts.p, pts, bpts, hipMemcpyHostToDevice, ctx->stream));
     }
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
     SET_HIP(s->desc8.reserve((size_t)r16 * 128));
@@ -1470,24 +1496,17 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
     if ((nA > 0 && (!descA || !ptsA)) || (nB > 0 && (!descB || !ptsB)))
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: null input");
 
-    // two-image set: A then B
+    // two-image set: A then B.  The set and the result live in the context from call to call, so a
+    // sequence of calls (the reference matches frame after frame) allocates once.
     const int32_t counts[2] = {nA, nB};
-    std::vector<float> desc((size_t)(nA + nB) * dim);
-    std::vector<double> pts((size_t)(nA + nB) * 2);
-    if (nA) {
-        memcpy(desc.data(), descA, (size_t)nA * dim * sizeof(float));
-        memcpy(pts.data(), ptsA, (size_t)nA * 2 * sizeof(double));
-    }
-    if (nB) {
-        memcpy(desc.data() + (size_t)nA * dim, descB, (size_t)nB * dim * sizeof(float));
-        memcpy(pts.data() + (size_t)nA * 2, ptsB, (size_t)nB * 2 * sizeof(double));
-    }
+    const TwoParts parts = {{descA, descB}, {ptsA, ptsB}};
     sfm_imageset *set = nullptr;
-    int rc = sfm_imageset_create(ctx, 2, counts, desc.data(), pts.data(), dim, &set);
+    int rc = imageset_build(ctx, 2, counts, nullptr, nullptr, dim, false, &set, nullptr, &ctx->pair_set, &parts);
     if (rc != SFM_OK) return rc;
-    sfm_match_result *res = nullptr;
+    ctx->pair_set = set;
     const int32_t pl[2] = {0, 1};
-    rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &res, true);
+    rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &ctx->pair_result, true);
+    sfm_match_result *res = ctx->pair_result;
     int64_t total = 0;
     if (rc == SFM_OK) rc = sfm_match_result_total(res, &total);
     if (rc == SFM_OK && total > capacity) {
@@ -1507,9 +1526,15 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
             rc = SFM_ERR_HIP;
         }
     }
-    sfm_match_result_destroy(res);
-    sfm_imageset_destroy(set);
     return rc;
+}
+
+void sfm_pair_match_free(sfm_ctx *ctx)
+{
+    if (ctx->pair_result) sfm_match_result_destroy(ctx->pair_result);
+    if (ctx->pair_set) sfm_imageset_destroy(ctx->pair_set);
+    ctx->pair_result = nullptr;
+    ctx->pair_set = nullptr;
 }
 
 extern "C" int sfm_match_result_stats_ex(sfm_match_result *res, int64_t *stats4_out)

@@ -258,3 +258,23 @@ def test_norm_square_root_is_correctly_rounded(ctx, oracle):
     for thr in (1.0, 0.99999994, 0.9999999):
         check_pair(ctx, oracle, a, p, a.copy(), p, thr)
     assert len(ctx.match_pair(a, p, a.copy(), p, threshold=1.0)) == 0
+
+
+def test_repeated_pair_calls_reuse_their_buffers(ctx, oracle):
+    """sfm_match_pair keeps its device tables in the context: calls of changing size, descriptor length
+    and value range (byte-valued or not) in a row must each give the reference's list."""
+    rng = np.random.default_rng(123)
+    for nA, nB, dim, integer in [(900, 700, 128, True), (50, 1300, 128, False), (1300, 40, 64, True), (0, 10, 128, True),
+                                 (600, 600, 128, True), (300, 300, 7, False)]:
+        base = rng.integers(0, 200, size=(max(nA, nB, 1), dim)).astype(np.float32)
+        A = base[:nA] + (0 if integer else rng.normal(0, 0.3, size=(nA, dim)).astype(np.float32))
+        B = base[:nB][::-1].copy() + (0 if integer else rng.normal(0, 0.3, size=(nB, dim)).astype(np.float32))
+        pA, pB = rng.uniform(0, 100, size=(nA, 2)), rng.uniform(0, 100, size=(nB, 2))
+        got, m1, m2 = ctx.match_pair(A, pA, B, pB, threshold=0.9, max_dist_sq=1e8, return_best=True)
+        exp, e1, e2 = oracle.match(A, pA, B, pB, threshold=0.9, max_dist_sq=1e8)
+        assert np.array_equal(got, exp) and np.array_equal(m1, e1) and np.array_equal(m2, e2), (nA, nB, dim)
+    with pytest.raises(capi.SfmError):
+        ctx.match_pair(np.zeros((4, 200), np.float32), np.zeros((4, 2)), np.zeros((4, 200), np.float32), np.zeros((4, 2)))
+    A = rng.integers(1, 200, size=(64, 128)).astype(np.float32)
+    got = ctx.match_pair(A, np.zeros((64, 2)), A, np.zeros((64, 2)), threshold=0.9)  # the call after a refused one
+    assert got.tolist() == [[i, i] for i in range(64)]
