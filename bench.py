@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--no-extensions", action="store_true", help="skip the modes the reference has no counterpart for")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="8192x8192 pairs the CPU baseline matches (stops after 25 s)")
     args = ap.parse_args()
 
@@ -196,6 +197,8 @@ def main():
     # ---- secondary: the stages chained on the device (default-run stand-in) --------------------
     if not args.no_pipeline and world == 1:
         out["pipeline"] = bench_pipeline(ctx, args)
+    if not args.no_extensions and world == 1:
+        out["extensions"] = bench_extensions(ctx, args)
 
     # ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -218,6 +221,39 @@ def measured_traffic(pairs_per_launch, bound="int8"):
     with open(path) as f:
         t = json.load(f)
     return round(t["hbm_bytes_per_pair"] * pairs_per_launch)
+
+
+def bench_extensions(ctx, args):
+    """Modes with no counterpart in the reference (checked against this repository's CPU restatement only):
+    binary descriptors under the Hamming distance, 40 images x features x 256 bit, exhaustive pairs."""
+    from sfm_amd import capi
+    rng = np.random.default_rng(0)
+    n, n_img = args.features, 40
+    pool = rng.integers(0, 256, size=(2 * n, 32), dtype=np.uint8)
+    desc, pts = [], []
+    for _ in range(n_img):
+        pick = rng.choice(len(pool), size=n, replace=False)
+        desc.append(pool[pick] ^ np.packbits(rng.random((n, 256)) < 0.05, axis=1))
+        pts.append(rng.uniform(0, 4000, size=(n, 2)))
+    s = capi.BinarySet(ctx, np.full(n_img, n, np.int32), np.concatenate(desc), np.concatenate(pts))
+    pl = np.array([(a, b) for a in range(n_img) for b in range(a + 1, n_img)], np.int32)
+    res = s.match(pl, max_distance=64)
+    ctx.synchronize()
+    reps = max(1, args.steps)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = s.match(pl, max_distance=64, result=res)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ms, launches = ctx.last_kernel_ms(0)
+    out = {"hamming": {
+        "workload": f"{n_img} images x {n} x 256-bit descriptors, exhaustive pairs ({len(pl)}), max distance 64",
+        "pairs_per_s": round(len(pl) / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+        "sign_kernel_ms": round(ms, 3), "sign_kernel_POPs": round(len(pl) * n * n * 512 / (ms * 1e-3) / 1e15, 3),
+        "dtype": "i8 signs on MFMA, popcount re-score", "matches_per_pair": round(res.total() / len(pl), 1)}}
+    res.close()
+    s.close()
+    return out
 
 
 def bench_pipeline(ctx, args):
