@@ -362,7 +362,7 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
         SFM_HIP(ctx, res->cand.reserve((size_t)chunkPairs * candCap * sizeof(uint2)));
         SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * maxQueues * sizeof(int)));
     }
-    SFM_HIP(ctx, res->pairOvf.reserve((size_t)chunkPairs * sizeof(int)));
+    SFM_HIP(ctx, res->pairOvf.reserve((size_t)(chunkPairs + 4) * sizeof(int)));
     SFM_HIP(ctx, res->pairRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
     SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, res->pairs.reserve((size_t)(outCap ? outCap : 1) * sizeof(int2)));
@@ -389,6 +389,7 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
         m.cand = res->cand.as<uint2>();
         m.candCount = res->candCount.as<int>();
         m.pairOvf = res->pairOvf.as<int>();
+        m.flagCount = res->pairOvf.as<int>() + chunkPairs;
         m.maxQueues = maxQueues;
         m.candCap = candCap;
         m.blockRows = SIM_ROWS_PER_BLOCK;
@@ -408,7 +409,7 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
             m.pairs = g.pairs;
             m.work = res->work.as<int2>() + workBase[ci];
             SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * maxQueues * sizeof(int), st));
-            SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)np * sizeof(int), st));
+            SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
             SFM_HIP(ctx, sfm_span_begin(ctx, 0));
             sfm_launch_sim_signs(m, workCount[ci], st);
             SFM_HIP(ctx, sfm_span_end(ctx, 0));

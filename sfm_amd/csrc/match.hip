@@ -486,8 +486,8 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // OCC = blocks per CU the register budget is set for.  FORM selects the arithmetic (the int8 forms have strict instances only).
 // ABL: timing-only ablations with wrong results: bit 0 = no staging and no barrier, bit 1 = no
 // candidate test.
-template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
-__global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
+template <int FORM, bool DOT, bool GENERAL, int ABL>
+__device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem)
 {
     // FORM 0: fp16 rows of 256 B; 1: int8 rows of 128 B; 2: int8 rows of 256 B (256 signs of a binary descriptor)
     constexpr bool I8 = FORM != 0;       // int8 MFMA, int32 sums
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? SIM_BN : 1];
     __shared__ unsigned rowBound[GENERAL ? SIM_BLOCK_ROWS : 1];
 
-    const int2 w = g.work[blockIdx.x];
+    const int2 w = g.work[workItem];
     if (w.x < 0) return;
     if (g.onlyFlagged && g.pairOvf[w.x] != g.onlyFlagged) return; // later passes: pairs an earlier pass gave up on
     PairRec pr = g.pairs[w.x];
@@ -645,7 +645,31 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
     }
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
-        if (wq.n > wq.cap) g.pairOvf[pr.chunkLocal] = GENERAL ? 2 : (I8 ? 3 : 1);
+        if (wq.n > wq.cap) {
+            const int flag = GENERAL ? 2 : (I8 ? 3 : 1);
+            g.pairOvf[pr.chunkLocal] = flag;
+            atomicAdd(&g.flagCount[flag], 1); // "some pair carries this flag", for the passes that walk the list
+        }
+    }
+}
+
+// One work item per block: the pass every pair takes.
+template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
+__global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
+{
+    sim_block<FORM, DOT, GENERAL, ABL>(g, blockIdx.x);
+}
+
+// The later passes of the cosine metric redo flagged pairs only, usually none: a grid that just fills the
+// device walks the work list instead of launching a block per item to find that out.  Items b and b + 8
+// stay on one XCD as long as the grid is a multiple of 8.
+template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
+__global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_walk_kernel(const MatchArgs g)
+{
+    if (g.onlyFlagged && g.flagCount[g.onlyFlagged] == 0) return; // nothing to redo
+    for (int item = blockIdx.x; item < g.nWork; item += gridDim.x) {
+        sim_block<FORM, DOT, GENERAL, ABL>(g, item);
+        __syncthreads(); // LDS of the item is free before the next one stages into it
     }
 }
 
@@ -657,7 +681,7 @@ struct SimVariant {
 };
 static const SimVariant kSimVariants[] = {
     {match_sim_kernel<4, false, false, false, 0>, nullptr, "fp16 bound"},                                       // 0
-    {match_sim_kernel<5, true, false, false, 0>, match_sim_kernel<4, false, false, false, 0>, "int8 bound"},    // 1: default
+    {match_sim_kernel<5, true, false, false, 0>, match_sim_walk_kernel<3, false, false, false, 0>, "int8 bound"},    // 1: default
     {match_sim_kernel<4, false, false, false, 2>, nullptr, "fp16, no candidate test (timing only)"},            // 2
     {match_sim_kernel<4, false, false, false, 3>, nullptr, "fp16, neither staging nor test (timing only)"},     // 3
     {match_sim_kernel<5, true, false, false, 2>, nullptr, "int8, no candidate test (timing only)"},             // 4
@@ -670,7 +694,7 @@ void sfm_launch_sim_signs(const MatchArgs &g, int blocks, hipStream_t st)
     hipLaunchKernelGGL((match_sim_kernel<4, 2, false, false, 0>), dim3(blocks), dim3(SIM_WAVES * 64), 0, st, g);
 }
 
-static void (*const kSimGeneral)(const MatchArgs) = match_sim_kernel<2, false, false, true, 0>;
+static void (*const kSimGeneral)(const MatchArgs) = match_sim_walk_kernel<2, false, false, true, 0>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
@@ -1280,7 +1304,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->cand.reserve((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)));
     const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
     SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * maxQueues * sizeof(int)));
-    SFM_HIP(ctx, res->pairOvf.reserve((size_t)chunkPairs * sizeof(int)));
+    SFM_HIP(ctx, res->pairOvf.reserve((size_t)(chunkPairs + 4) * sizeof(int))); // flags, then how often each value was set
     SFM_HIP(ctx, res->best.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(u64)));
     SFM_HIP(ctx, res->ovfList.reserve((size_t)(chunkPairs + 1) * sizeof(int)));
     SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
@@ -1304,6 +1328,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.cand = res->cand.as<uint2>();
     g.candCount = res->candCount.as<int>();
     g.pairOvf = res->pairOvf.as<int>();
+    g.flagCount = res->pairOvf.as<int>() + chunkPairs;
     g.maxQueues = maxQueues;
     g.blockRows = BLOCK_ROWS;
     g.wavesPerBlock = wavesPerBlock;
@@ -1340,8 +1365,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             SFM_HIP(ctx, hipMemsetAsync(res->best.p, 0, (size_t)bestLen * sizeof(u64), st));
         }
         SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * maxQueues * sizeof(int), st));
-        SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)np * sizeof(int), st));
+        SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
         const int nblk = chunkWorkCount[0][ci];
+        const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
         if (nblk > 0) {
             const bool cosine = metric == SFM_METRIC_COSINE;
             if (cosine) {
@@ -1352,7 +1378,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             }
             if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 g.onlyFlagged = 3;
-                hipLaunchKernelGGL(variant.strict16, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
+                g.nWork = nblk;
+                hipLaunchKernelGGL(variant.strict16, dim3(std::min(nblk, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
             }
             // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
             // orientations.  Dot: every pair takes this path.
@@ -1361,7 +1388,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 g.orient = o;
                 g.work = workList[o];
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0));
-                hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(chunkWorkCount[o][ci]),
+                g.nWork = chunkWorkCount[o][ci];
+                hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(cosine ? std::min(g.nWork, walkGrid) : g.nWork),
                                    dim3(SIM_WAVES * 64), 0, st, g);
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0));
             }

@@ -36,7 +36,9 @@ struct MatchArgs {
     uint2 *cand;          // [pairs in chunk][candCap]
     int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
     int *pairOvf;         // [pairs in chunk]: a slice overflowed in 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
+    int *flagCount;       // [4]: how often a flag value was set in this chunk (only zero / non-zero matters)
     int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
+    int nWork;            // entries of the work list (passes that walk it)
     int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
     int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
     u64 *best;            // row keys and column keys of the chunk
