@@ -74,13 +74,70 @@ def loss_cases():
                 pt=np.array([r["pt"] for r in rows]), loss=np.array([r["loss"] for r in rows]))
 
 
+def ratio_cases():
+    """matchTwoSided plus the second-best ratio test (an extension: the reference has none)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from test_match_ratio_gpu import crowded_pair
+    cases = {}
+    for name, seed, n, integer, thr, gate, ratio in [("crowded_400_r080", 5, 400, True, 0.9, 400.0 ** 2, 0.8),
+                                                     ("crowded_300_float_r095", 6, 300, False, 0.9, 1e8, 0.95)]:
+        A, pA, B, pB = crowded_pair(seed, n=n, integer=integer)
+        pairs, m1, m2 = oracle.match(A, pA, B, pB, threshold=thr, max_dist_sq=gate, ratio=ratio)
+        cases[name] = dict(descA=A, ptsA=pA, descB=B, ptsB=pB, threshold=np.float32(thr), max_dist_sq=np.float32(gate),
+                           ratio=np.float32(ratio), pairs=pairs, matches1=m1, matches2=m2)
+    return cases
+
+
+def hamming_cases():
+    """Binary descriptors under the Hamming distance (an extension: the reference has none)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from test_hamming_gpu import binary_views
+    cases = {}
+    for name, seed, n, nbytes, maxd, gate in [("256bit_500", 1, 500, 32, 48, 1e8), ("128bit_300_gate", 2, 300, 16, 30, 80.0 ** 2),
+                                              ("512bit_200", 3, 200, 64, 110, 1e8)]:
+        descs, ptss, _ = binary_views(seed, 2, n, nbytes)
+        pairs, m1, m2 = oracle.match_hamming(descs[0], ptss[0], descs[1], ptss[1], max_distance=maxd, max_dist_sq=gate)
+        cases[name] = dict(descA=descs[0], ptsA=ptss[0], descB=descs[1], ptsB=ptss[1], max_distance=np.int32(maxd),
+                           max_dist_sq=np.float32(gate), pairs=pairs, matches1=m1, matches2=m2)
+    return cases
+
+
+def chain_cases():
+    """Scale chaining and running point average, scene.cpp:301-421."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from chain_cases import sequence
+    cases = {}
+    for name, seed, steps, tracks, cap in [("12_steps_400_tracks", 7, 12, 400, 15.0), ("5_steps_capped", 8, 5, 150, 0.6)]:
+        off, ids, pts, poses = sequence(seed, steps, tracks, behind=0.1, far=0.05)
+        start = np.eye(4)
+        start[:3, 3] = [0.5, -1.0, 2.0]
+        r = oracle.scale_chain(off, ids, pts, poses, start_pose=start, max_translation=cap, n_tracks=tracks)
+        cases[name] = dict(offsets=off, track_ids=ids, points=pts, poses=poses, start=start, max_translation=cap,
+                           n_tracks=np.int32(tracks), **r)
+    return cases
+
+
+def refit_cases():
+    """eightPointAlgorithm on all points, eightPoint.cpp:57-223."""
+    cases = {}
+    for name, n, seed in [("n40", 40, 11), ("n600", 600, 12)]:
+        tv = synth.two_view(n, inlier_ratio=1.0, seed=seed, noise_px=0.2)
+        pose, points = oracle.eight_point(tv["x"], tv["y"])[:2]
+        cases[name] = dict(x=tv["x"], y=tv["y"], pose=pose, points=points)
+    return cases
+
+
 def main():
     oracle.build()
-    for name, c in matcher_cases().items():
-        np.savez_compressed(os.path.join(OUT, f"match_{name}.npz"), **c)
-    for name, c in ransac_cases().items():
-        np.savez_compressed(os.path.join(OUT, f"ransac_{name}.npz"), **c)
-    np.savez_compressed(os.path.join(OUT, "loss_cases.npz"), **loss_cases())
+    groups = [("match_", matcher_cases), ("ransac_", ransac_cases), ("ratio_", ratio_cases), ("hamming_", hamming_cases),
+              ("chain_", chain_cases), ("refit_", refit_cases)]
+    for prefix, make in groups:
+        for name, c in make().items():
+            path = os.path.join(OUT, f"{prefix}{name}.npz")
+            if not os.path.exists(path) or "--all" in sys.argv:  # committed vectors stay as they are
+                np.savez_compressed(path, **c)
+    if not os.path.exists(os.path.join(OUT, "loss_cases.npz")) or "--all" in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "loss_cases.npz"), **loss_cases())
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
 
 

@@ -38,6 +38,40 @@ def test_ransac_golden(oracle, path):
     assert np.array_equal(pose12, g["pose12"]) and np.array_equal(cand, g["candidate"])
 
 
+@pytest.mark.parametrize("path", golden("ratio_"), ids=os.path.basename)
+def test_ratio_golden(oracle, path):
+    g = np.load(path)
+    pairs, m1, m2 = oracle.match(g["descA"], g["ptsA"], g["descB"], g["ptsB"], threshold=float(g["threshold"]),
+                                 max_dist_sq=float(g["max_dist_sq"]), ratio=float(g["ratio"]))
+    assert np.array_equal(pairs, g["pairs"]) and np.array_equal(m1, g["matches1"]) and np.array_equal(m2, g["matches2"])
+    assert 20 < len(pairs) < len(g["descA"])
+
+
+@pytest.mark.parametrize("path", golden("hamming_"), ids=os.path.basename)
+def test_hamming_golden(oracle, path):
+    g = np.load(path)
+    pairs, m1, m2 = oracle.match_hamming(g["descA"], g["ptsA"], g["descB"], g["ptsB"], max_distance=int(g["max_distance"]),
+                                         max_dist_sq=float(g["max_dist_sq"]))
+    assert np.array_equal(pairs, g["pairs"]) and np.array_equal(m1, g["matches1"]) and np.array_equal(m2, g["matches2"])
+    assert len(pairs) > 20
+
+
+@pytest.mark.parametrize("path", golden("chain_"), ids=os.path.basename)
+def test_chain_golden(oracle, path):
+    g = np.load(path)
+    r = oracle.scale_chain(g["offsets"], g["track_ids"], g["points"], g["poses"], start_pose=g["start"],
+                           max_translation=float(g["max_translation"]), n_tracks=int(g["n_tracks"]))
+    for k in ("extrinsics", "points3d", "counts", "scale"):
+        assert np.array_equal(r[k], g[k]), k
+
+
+@pytest.mark.parametrize("path", golden("refit_"), ids=os.path.basename)
+def test_refit_golden(oracle, path):
+    g = np.load(path)
+    pose, points = oracle.eight_point(g["x"], g["y"])[:2]
+    assert np.array_equal(pose, g["pose"]) and np.array_equal(points, g["points"])
+
+
 def test_loss_golden(oracle):
     g = np.load(os.path.join(GOLDEN, "loss_cases.npz"))
     for o1, o2, pt, want in zip(g["obs1"], g["obs2"], g["pt"], g["loss"]):
