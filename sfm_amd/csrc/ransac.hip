@@ -46,7 +46,7 @@ struct RansacArgs {
     const int64_t *inlOff;  // [P+1]
     int32_t *inliers;
     double K[9]; // column-major
-    double Ki[4]; // inverse of K's upper-left 2x2 block, row-major (valid when filter != 0)
+    double Ki[4]; // pre-test constants (valid when filter != 0): 1/fx, 1/fy, 1e-6/min(fx,fy)^2, max(fx,fy)^2
     int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
     double maxSqErr;
     double successProb;
@@ -489,11 +489,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     const double thr = g.maxSqErr;
     const bool filterOn = g.filter != 0;
     // fp32 splats for the pre-test
-    f32x2 Ef[9], Kif[4];
+    // rows 0 and 1 of E divided by fx, fy: the line of a correspondence comes out in pixel metric
+    f32x2 Ef[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) Ef[i] = splat((float)E[i / 3][i % 3]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) Kif[i] = splat((float)g.Ki[i]);
+    for (int i = 0; i < 9; i++) Ef[i] = splat((float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] : (i < 6 ? g.Ki[1] : 1.0))));
+    const f32x2 fmax2 = splat((float)g.Ki[3]);
     const f32x2 thr16 = splat((float)(16.0 * thr));
 
     int count = 0;
@@ -536,10 +536,10 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const bool real = q < m;
                 d[0] = real ? (float)r[0] : 0.0f;
                 d[2] = real ? (float)r[1] : 0.0f;
-                d[4] = real ? (float)r[2] : 0.0f;
-                d[6] = real ? (float)r[3] : 0.0f;
-                d[8] = real ? (float)r[9] : 0.0f;
-                d[10] = real ? (float)r[4] : 0.0f;
+                d[4] = real ? (float)(r[2] * K[0]) : 0.0f; // fx x2, fy y2: the observation in pixels off the centre
+                d[6] = real ? (float)(r[3] * K[4]) : 0.0f;
+                d[8] = real ? (float)(r[9] * g.Ki[2]) : 0.0f;  // |x1h|^2 * 1e-6 / min(fx,fy)^2, or inf
+                d[10] = real ? (float)(r[4] * 1e-8) : 0.0f;    // |x2h|^2 * 1e-8
             }
             __syncthreads();
         }
@@ -555,30 +555,32 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             // Pre-test, in packed fp32 (two correspondences per instruction).  Whatever depth the
             // triangulation picks, the point lies on the ray of x1, so its image in camera 2 lies
             // on the epipolar line of x1; the camera-2 reprojection error is therefore at least
-            // the distance from the observation to that line.  If the fp32 estimate of that
-            // distance is at least four times sqrt(maxSquaredError), the correspondence cannot be
-            // an inlier of this hypothesis and the exact evaluation is skipped.  Guards keep the
-            // estimate within a few per cent of the truth, far inside the factor of four: the
-            // line direction must be well defined (|m01| >= 1e-3 |x1h|: fp32 noise in m is
-            // ~1e-7 |x1h|, and near the epipole the reference's own projection is unstable), the
-            // residual must stand clear of its rounding noise (|num| >= 1e-4 |x2h| |m|), and the
-            // observation must be an ordinary pixel (r9 = inf otherwise).  NaNs fail every test.
+            // the distance from the observation to that line.  With K = [fx 0 cx; 0 fy cy; 0 0 1]
+            // and m = E x1h, that distance in pixels is (x2 m0 + y2 m1 + m2) / sqrt(q),
+            // q = (m0/fx)^2 + (m1/fy)^2; the kernel works with m0/fx, m1/fy (E's rows pre-divided)
+            // and fx x2, fy y2 (staged per correspondence).  If the fp32 estimate of the distance is
+            // at least four times sqrt(maxSquaredError), the correspondence cannot be an inlier of
+            // this hypothesis and the exact evaluation is skipped.  Guards keep the estimate
+            // within a few per cent of the truth, far inside the factor of four: the line
+            // direction must be well defined (q >= 1e-6 |x1h|^2 / min(fx,fy)^2, which implies
+            // |m01| >= 1e-3 |x1h|: fp32 noise in m is ~1e-7 |x1h|, and near the epipole the
+            // reference's own projection is unstable), the residual must stand clear of its
+            // rounding noise (num^2 >= 1e-8 |x2h|^2 (max(fx,fy)^2 q + m2^2) >= 1e-8 |x2h|^2 |m|^2),
+            // and the observation must be an ordinary pixel (the staged guard is inf otherwise).
+            // NaNs fail every test.
             for (int kk = 0; kk < m; kk += 2) {
                 const f32x2 *rp = reinterpret_cast<const f32x2 *>(rec32 + (kk >> 1) * 12);
-                const f32x2 x1 = rp[0], y1 = rp[1], x2 = rp[2], y2 = rp[3], r9 = rp[4], r4 = rp[5];
+                const f32x2 x1 = rp[0], y1 = rp[1], u2 = rp[2], v2 = rp[3], g1 = rp[4], r4c = rp[5];
                 const f32x2 m0 = pk_fma(Ef[0], x1, pk_fma(Ef[1], y1, Ef[2]));
                 const f32x2 m1 = pk_fma(Ef[3], x1, pk_fma(Ef[4], y1, Ef[5]));
                 const f32x2 m2 = pk_fma(Ef[6], x1, pk_fma(Ef[7], y1, Ef[8]));
-                const f32x2 num = pk_fma(x2, m0, pk_fma(y2, m1, m2));
-                const f32x2 l0 = pk_fma(Kif[0], m0, Kif[2] * m1); // (K^-T m) rows 0, 1: the line in pixels
-                const f32x2 l1 = pk_fma(Kif[1], m0, Kif[3] * m1);
-                const f32x2 den2 = pk_fma(l0, l0, l1 * l1) * thr16;
-                const f32x2 m01 = pk_fma(m0, m0, m1 * m1);
-                const f32x2 msq = pk_fma(m2, m2, m01);
+                const f32x2 num = pk_fma(u2, m0, pk_fma(v2, m1, m2));
+                const f32x2 q = pk_fma(m0, m0, m1 * m1);
+                const f32x2 den2 = q * thr16;
                 const f32x2 n2 = num * num;
-                const f32x2 g1 = r9 * 1e-6f, g2 = (r4 * 1e-8f) * msq;
-                const bool skip0 = n2.x >= den2.x && m01.x >= g1.x && n2.x >= g2.x;
-                const bool skip1 = n2.y >= den2.y && m01.y >= g1.y && n2.y >= g2.y;
+                const f32x2 g2 = r4c * pk_fma(m2, m2, fmax2 * q);
+                const bool skip0 = n2.x >= den2.x && q.x >= g1.x && n2.x >= g2.x;
+                const bool skip1 = n2.y >= den2.y && q.y >= g1.y && n2.y >= g2.y;
                 if (!skip0) pend[npend++][tid] = (unsigned short)kk;
                 else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
                 if (kk + 1 < m) {
@@ -1246,18 +1248,18 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.inliers = b->inliers.as<int32_t>();
     for (int i = 0; i < 9; i++) g.K[i] = K[i];
     {
-        // K column-major: K(r,c) = K[r + 3c].  The pre-test needs the last row to be (0, 0, 1)
-        // (then observations K*(x,y,1) are pixels with unit third component) and an invertible
-        // upper-left block.
-        const double k00 = K[0], k10 = K[1], k01 = K[3], k11 = K[4];
-        const double det2 = k00 * k11 - k01 * k10;
-        const bool ok = K[2] == 0.0 && K[5] == 0.0 && K[8] == 1.0 && det2 != 0.0 && std::isfinite(det2) &&
-                        std::isfinite(1.0 / det2) && ctx->ransac_filter != 0;
+        // K column-major: K(r,c) = K[r + 3c].  The pre-test needs K = [fx 0 cx; 0 fy cy; 0 0 1] with
+        // positive focal lengths: observations K*(x,y,1) are then pixels, and the epipolar line of a
+        // hypothesis keeps a simple form in them (see the scoring kernel).
+        const double fx = K[0], fy = K[4];
+        const bool ok = K[2] == 0.0 && K[5] == 0.0 && K[8] == 1.0 && K[1] == 0.0 && K[3] == 0.0 && fx > 0.0 && fy > 0.0 &&
+                        std::isfinite(fx) && std::isfinite(fy) && std::isfinite(1.0 / fx) && std::isfinite(1.0 / fy) &&
+                        ctx->ransac_filter != 0;
         g.filter = ok ? 1 : 0;
-        g.Ki[0] = ok ? k11 / det2 : 0.0;  // Kinv(0,0)
-        g.Ki[1] = ok ? -k01 / det2 : 0.0; // Kinv(0,1)
-        g.Ki[2] = ok ? -k10 / det2 : 0.0; // Kinv(1,0)
-        g.Ki[3] = ok ? k00 / det2 : 0.0;  // Kinv(1,1)
+        g.Ki[0] = ok ? 1.0 / fx : 0.0;
+        g.Ki[1] = ok ? 1.0 / fy : 0.0;
+        g.Ki[2] = ok ? 1e-6 / (std::min(fx, fy) * std::min(fx, fy)) : 0.0; // guard on the line direction
+        g.Ki[3] = ok ? std::max(fx, fy) * std::max(fx, fy) : 0.0;          // bound of |m|^2 from the scaled line
     }
     g.maxSqErr = maxSqErr;
     g.successProb = successProb;

@@ -218,6 +218,33 @@ def test_pretest_is_off_for_unusual_intrinsics(ctx, oracle):
     assert_same_run(got, exp)
 
 
+@pytest.mark.parametrize("case", ["skew", "fx_ne_fy", "tiny_focal", "huge_focal", "tight_threshold", "negative_fx"])
+def test_pretest_with_other_intrinsics(ctx, oracle, case):
+    """The pre-test works in pixel metric with fx and fy folded into the hypothesis; whatever K is, counts
+    and error sums stay those of evaluating every cell."""
+    tv = synth.two_view(900, inlier_ratio=0.4, seed=190)
+    K = tv["K"].copy()
+    thr = 1.0
+    if case == "skew":
+        K[0, 1] = 3.5
+    elif case == "fx_ne_fy":
+        K[0, 0], K[1, 1] = 0.6 * K[0, 0], 1.7 * K[1, 1]
+    elif case == "tiny_focal":
+        K[0, 0] = K[1, 1] = 2.0
+        K[0, 2] = K[1, 2] = 0.5
+        thr = 1e-6
+    elif case == "huge_focal":
+        K[0, 0] = K[1, 1] = 4e5
+    elif case == "tight_threshold":
+        thr = 1e-4
+    elif case == "negative_fx":
+        K[0, 0] = -K[0, 0]
+    S = synth.sample_table(900, 256, seed=191)
+    got = ctx.ransac_pair(tv["x"], tv["y"], K, S, max_sq_err=thr, adaptive=False)
+    exp = oracle.ransac(tv["x"], tv["y"], K, S, max_sq_err=thr, adaptive=False)
+    assert_same_run(got, exp)
+
+
 @pytest.mark.parametrize("first_slice", [64, 256, 1024])
 def test_sliced_adaptive_batch_equals_one_pass(ctx, oracle, first_slice):
     """With the adaptive cap on, a batch scores its sample rows in growing slices and pairs whose in-order
