@@ -28,6 +28,7 @@
 #define SCORE_CH 256 // correspondences staged in LDS per step
 #define SCORE_QCAP 8 // per-lane queue of correspondences awaiting exact evaluation
 #define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
+#define SCORE_CH32 1024 // correspondences staged per step by the instances that run the pre-test
 
 struct RansacArgs {
     const double2 *x;
@@ -35,6 +36,7 @@ struct RansacArgs {
     const int64_t *corrOff; // [P+1], device
     const int32_t *samples; // [P][H][8]
     double *rec;            // [total][REC_D]
+    float *rec32;           // pre-test records in fp32, pairs of correspondences interleaved (see rec32_start)
     double *pose12;         // [P][H][12] R row-major then T
     int *counts;            // [P][H]
     double *toterr;         // [P][H]
@@ -51,6 +53,7 @@ struct RansacArgs {
     double maxSqErr;
     double successProb;
     int H;
+    int nPairs;
     int adaptive;
     int loss;
     // Hypotheses are evaluated in phases [hBegin, hEnd): a pair whose in-order scan has already
@@ -151,6 +154,10 @@ __device__ __forceinline__ double sampson_loss(const double *K, const double E[3
 // ---------------------------------------------------------------------------------------
 // prep
 // ---------------------------------------------------------------------------------------
+// First float of pair p's pre-test records (its correspondences start at row `base`): a multiple of 12,
+// and regions of consecutive pairs do not overlap (each takes 12 * ceil(n / 2) floats).
+__host__ __device__ inline size_t rec32_start(int64_t base, int p) { return (size_t)12 * (size_t)((base + p + 1) / 2); }
+
 __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, int64_t total)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,6 +177,29 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     const double big = 1e6;
     const bool tame = fabs(r[5]) <= big && fabs(r[6]) <= big && fabs(r[7]) <= big && fabs(r[8]) <= big;
     r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
+    if (!g.filter) return;
+    // fp32 record of the pre-test: x1, y1, fx x2, fy y2 (the observation in pixels off the centre),
+    // |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 * 1e-8.  Correspondences 2j and 2j + 1 of a pair
+    // share twelve floats, field by field, so that one packed instruction serves both.
+    int lo = 0, hi = g.nPairs; // the pair that owns correspondence k
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (g.corrOff[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int64_t base = g.corrOff[lo];
+    const int kk = (int)(k - base);
+    const int n = (int)(g.corrOff[lo + 1] - base);
+    float *d = g.rec32 + rec32_start(base, lo) + (size_t)(kk >> 1) * 12 + (kk & 1);
+    d[0] = (float)r[0];
+    d[2] = (float)r[1];
+    d[4] = (float)(r[2] * g.K[0]);
+    d[6] = (float)(r[3] * g.K[4]);
+    d[8] = (float)(r[9] * g.Ki[2]);
+    d[10] = (float)(r[4] * 1e-8);
+    if (kk == n - 1 && !(kk & 1)) { // odd count: the last record's partner is all zeros (never read as a result)
+#pragma unroll
+        for (int f = 0; f < 6; f++) d[2 * f + 1] = 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -455,12 +485,18 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 // associative), so instead of accumulating, the block writes every cell of
 // errBuf[(correspondence, row)]: the error of an inlier, a negative NaN pattern otherwise, and
 // ransac_sum_kernel adds the inliers' errors up in order.
-template <int LOSS, bool SPLIT>
+// FILTER: the instance that runs the pre-test (reprojection loss, plain intrinsics).  It stages only the
+// fp32 records (24 B per correspondence, SCORE_CH32 at a time, prepared once by ransac_prep_kernel) and
+// fetches the fp64 record of the rare survivor from global memory; the other instances evaluate every
+// cell and stage the fp64 records.
+template <int LOSS, bool SPLIT, bool FILTER>
 __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, double *__restrict__ errBuf)
 {
-    __shared__ __attribute__((aligned(16))) double rec[SCORE_CH * REC_D];
-    __shared__ unsigned short pend[SCORE_QCAP][256]; // per-lane queues of chunk-local correspondence indices
-    __shared__ __attribute__((aligned(16))) float rec32[(SCORE_CH / 2) * 12];
+    static_assert(!FILTER || LOSS != SFM_LOSS_SAMPSON, "the pre-test bounds the reprojection error");
+    constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
+    __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
+    __shared__ unsigned short pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of chunk-local correspondence indices
+    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 2) * 12 : 4];
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
     const int h = g.hBegin + blockIdx.x * 256 + tid;
@@ -487,7 +523,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
 #pragma unroll
     for (int i = 0; i < 9; i++) K[i] = g.K[i];
     const double thr = g.maxSqErr;
-    const bool filterOn = g.filter != 0;
     // fp32 splats for the pre-test
     // rows 0 and 1 of E divided by fx, fy: the line of a correspondence comes out in pixel metric
     f32x2 Ef[9];
@@ -515,7 +550,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
         }
     };
     auto evaluate = [&](int kk) {
-        const double *r = rec + kk * REC_D;
+        const double *r = FILTER ? g.rec + (size_t)(base + kChunk + kk) * REC_D : rec + kk * REC_D;
         record(kk, reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]));
     };
     auto drain = [&]() {
@@ -523,33 +558,25 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             if (i < npend) evaluate(pend[i][tid]);
         npend = 0;
     };
-    for (int k0 = kBeg; k0 < kEnd; k0 += SCORE_CH) {
-        const int m = min(SCORE_CH, kEnd - k0);
+    const float *rec32g = FILTER ? g.rec32 + rec32_start(base, p) : nullptr;
+    for (int k0 = kBeg; k0 < kEnd; k0 += CH) {
+        const int m = min(CH, kEnd - k0);
         kChunk = k0;
-        const double2 *src = reinterpret_cast<const double2 *>(g.rec + (base + k0) * REC_D);
-        for (int q = tid; q < m * (REC_D / 2); q += 256) reinterpret_cast<double2 *>(rec)[q] = src[q];
-        __syncthreads();
-        if (LOSS != SFM_LOSS_SAMPSON && filterOn) { // fp32 copies for the pre-test, two correspondences interleaved
-            for (int q = tid; q < ((m + 1) & ~1); q += 256) {
-                float *d = rec32 + (q >> 1) * 12 + (q & 1);
-                const double *r = rec + q * REC_D;
-                const bool real = q < m;
-                d[0] = real ? (float)r[0] : 0.0f;
-                d[2] = real ? (float)r[1] : 0.0f;
-                d[4] = real ? (float)(r[2] * K[0]) : 0.0f; // fx x2, fy y2: the observation in pixels off the centre
-                d[6] = real ? (float)(r[3] * K[4]) : 0.0f;
-                d[8] = real ? (float)(r[9] * g.Ki[2]) : 0.0f;  // |x1h|^2 * 1e-6 / min(fx,fy)^2, or inf
-                d[10] = real ? (float)(r[4] * 1e-8) : 0.0f;    // |x2h|^2 * 1e-8
-            }
-            __syncthreads();
+        if (FILTER) { // k0 is even: whole twelve-float groups
+            const uint4 *src = reinterpret_cast<const uint4 *>(rec32g + (size_t)(k0 >> 1) * 12);
+            for (int q = tid; q < ((m + 1) >> 1) * 3; q += 256) reinterpret_cast<uint4 *>(rec32)[q] = src[q];
+        } else {
+            const double2 *src = reinterpret_cast<const double2 *>(g.rec + (base + k0) * REC_D);
+            for (int q = tid; q < m * (REC_D / 2); q += 256) reinterpret_cast<double2 *>(rec)[q] = src[q];
         }
+        __syncthreads();
         if (waveIdle) {
         } else if (LOSS == SFM_LOSS_SAMPSON) {
             for (int kk = 0; kk < m; kk++) {
                 const double *r = rec + kk * REC_D;
                 record(kk, sampson_loss(K, E, r[0], r[1], r[2], r[3]));
             }
-        } else if (!filterOn) {
+        } else if (!FILTER) {
             for (int kk = 0; kk < m; kk++) evaluate(kk);
         } else {
             // Pre-test, in packed fp32 (two correspondences per instruction).  Whatever depth the
@@ -1120,7 +1147,7 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32;
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
@@ -1134,7 +1161,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
-                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf};
+                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32};
     for (DevBuf *d : bufs) d->release();
     delete b;
 }
@@ -1220,6 +1247,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     }
     SFM_HIP(ctx, b->corrOff.reserve((P1 + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, b->rec.reserve((size_t)(total ? total : 1) * REC_D * sizeof(double)));
+    SFM_HIP(ctx, b->rec32.reserve((rec32_start(total, n_pairs) + 24) * sizeof(float)));
     SFM_HIP(ctx, b->pose12.reserve(PH * 12 * sizeof(double)));
     SFM_HIP(ctx, b->counts.reserve(PH * sizeof(int)));
     SFM_HIP(ctx, b->toterr.reserve(PH * sizeof(double)));
@@ -1236,6 +1264,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
 
     g.corrOff = b->corrOff.as<int64_t>();
     g.rec = b->rec.as<double>();
+    g.rec32 = b->rec32.as<float>();
+    g.nPairs = n_pairs;
     g.pose12 = b->pose12.as<double>();
     g.counts = b->counts.as<int>();
     g.toterr = b->toterr.as<double>();
@@ -1306,22 +1336,26 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             const int Z = split_factor(ctx, n_pairs, rows, total);
             SFM_HIP(ctx, sfm_span_begin(ctx, 1));
             const dim3 grid((rows + 255) / 256, n_pairs, Z);
+            const bool pretest = g.filter != 0 && loss != SFM_LOSS_SAMPSON;
+            double *eb = nullptr;
             if (Z > 1) {
                 SFM_HIP(ctx, b->errBuf.reserve(errBytes));
-                double *eb = b->errBuf.as<double>();
-                if (loss == SFM_LOSS_SAMPSON)
-                    hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON, true>), grid, dim3(256), 0, st, g, eb);
-                else
-                    hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION, true>), grid, dim3(256), 0, st, g, eb);
+                eb = b->errBuf.as<double>();
+            }
+            void (*score)(const RansacArgs, double *);
+            if (loss == SFM_LOSS_SAMPSON)
+                score = Z > 1 ? ransac_score_kernel<SFM_LOSS_SAMPSON, true, false> : ransac_score_kernel<SFM_LOSS_SAMPSON, false, false>;
+            else if (pretest)
+                score = Z > 1 ? ransac_score_kernel<SFM_LOSS_REPROJECTION, true, true> : ransac_score_kernel<SFM_LOSS_REPROJECTION, false, true>;
+            else
+                score = Z > 1 ? ransac_score_kernel<SFM_LOSS_REPROJECTION, true, false>
+                              : ransac_score_kernel<SFM_LOSS_REPROJECTION, false, false>;
+            hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
+            if (Z > 1) {
                 if ((int64_t)n_pairs * ((rows + 63) / 64) >= ctx->n_cus)
                     hipLaunchKernelGGL(ransac_sum_kernel<64>, dim3((rows + 63) / 64, n_pairs), dim3(SUM_THREADS), 0, st, g, eb);
                 else
                     hipLaunchKernelGGL(ransac_sum_kernel<16>, dim3((rows + 15) / 16, n_pairs), dim3(SUM_THREADS), 0, st, g, eb);
-            } else if (loss == SFM_LOSS_SAMPSON) {
-                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_SAMPSON, false>), grid, dim3(256), 0, st, g, (double *)nullptr);
-            } else {
-                hipLaunchKernelGGL((ransac_score_kernel<SFM_LOSS_REPROJECTION, false>), grid, dim3(256), 0, st, g,
-                                   (double *)nullptr);
             }
             SFM_HIP(ctx, sfm_span_end(ctx, 1));
         }
