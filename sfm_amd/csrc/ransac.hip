@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
     __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
     __shared__ unsigned short pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of chunk-local correspondence indices
-    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 2) * 12 : 4];
+    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 2 + 1) * 12 : 4];
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
     const int h = g.hBegin + blockIdx.x * 256 + tid;
@@ -595,9 +595,9 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             // rounding noise (num^2 >= 1e-8 |x2h|^2 (max(fx,fy)^2 q + m2^2) >= 1e-8 |x2h|^2 |m|^2),
             // and the observation must be an ordinary pixel (the staged guard is inf otherwise).
             // NaNs fail every test.
-            for (int kk = 0; kk < m; kk += 2) {
-                const f32x2 *rp = reinterpret_cast<const f32x2 *>(rec32 + (kk >> 1) * 12);
-                const f32x2 x1 = rp[0], y1 = rp[1], u2 = rp[2], v2 = rp[3], g1 = rp[4], r4c = rp[5];
+            // Two pairs of correspondences per iteration, their records fetched from LDS up front.
+            auto test_pair = [&](int kk, const f32x2 x1, const f32x2 y1, const f32x2 u2, const f32x2 v2, const f32x2 g1,
+                                 const f32x2 r4c) __attribute__((always_inline)) {
                 const f32x2 m0 = pk_fma(Ef[0], x1, pk_fma(Ef[1], y1, Ef[2]));
                 const f32x2 m1 = pk_fma(Ef[3], x1, pk_fma(Ef[4], y1, Ef[5]));
                 const f32x2 m2 = pk_fma(Ef[6], x1, pk_fma(Ef[7], y1, Ef[8]));
@@ -608,14 +608,25 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const f32x2 g2 = r4c * pk_fma(m2, m2, fmax2 * q);
                 const bool skip0 = n2.x >= den2.x && q.x >= g1.x && n2.x >= g2.x;
                 const bool skip1 = n2.y >= den2.y && q.y >= g1.y && n2.y >= g2.y;
-                if (!skip0) pend[npend++][tid] = (unsigned short)kk;
-                else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
+                if (kk < m) {
+                    if (!skip0) pend[npend++][tid] = (unsigned short)kk;
+                    else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
+                }
                 if (kk + 1 < m) {
                     if (!skip1) pend[npend++][tid] = (unsigned short)(kk + 1);
                     else if (SPLIT && active) errCol[(size_t)(kChunk + kk + 1) * rows] = none;
                 }
+            };
+            for (int kk = 0; kk < m; kk += 4) {
+                // (a chunk holds an even number of twelve-float groups' worth of LDS: reading one group
+                // past the last is harmless, its results are discarded by the kk < m tests)
+                const f32x2 *rp = reinterpret_cast<const f32x2 *>(rec32 + (kk >> 1) * 12);
+                const f32x2 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3], a4 = rp[4], a5 = rp[5];
+                const f32x2 b0 = rp[6], b1 = rp[7], b2 = rp[8], b3 = rp[9], b4 = rp[10], b5 = rp[11];
+                test_pair(kk, a0, a1, a2, a3, a4, a5);
+                test_pair(kk + 2, b0, b1, b2, b3, b4, b5);
                 // room for the next four: drain as soon as any lane of the wave holds more than four
-                if ((kk & 2) && __builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 4) != 0) drain();
+                if (__builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 4) != 0) drain();
             }
             drain(); // the queue indexes this chunk's records
         }
