@@ -608,6 +608,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const f32x2 g2 = r4c * pk_fma(m2, m2, fmax2 * q);
                 const bool skip0 = n2.x >= den2.x && q.x >= g1.x && n2.x >= g2.x;
                 const bool skip1 = n2.y >= den2.y && q.y >= g1.y && n2.y >= g2.y;
+                // most of the time no lane of the wave has a survivor: one uniform branch around the pushes
+                if (!SPLIT && __builtin_amdgcn_ballot_w64(!(skip0 && skip1)) == 0) return;
                 if (kk < m) {
                     if (!skip0) pend[npend++][tid] = (unsigned short)kk;
                     else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
