@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
     if (!g.filter) return;
     // fp32 record of the pre-test: x1, y1, fx x2, fy y2 (the observation in pixels off the centre),
-    // |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 * 1e-8.  Correspondences 2j and 2j + 1 of a pair
+    // |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 |x1h|^2 * 2e-8.  Correspondences 2j and 2j + 1 of a pair
     // share twelve floats, field by field, so that one packed instruction serves both.
     int lo = 0, hi = g.nPairs; // the pair that owns correspondence k
     while (hi - lo > 1) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     d[4] = (float)(r[2] * g.K[0]);
     d[6] = (float)(r[3] * g.K[4]);
     d[8] = (float)(r[9] * g.Ki[2]);
-    d[10] = (float)(r[4] * 1e-8);
+    d[10] = (float)((r[4] * r[9]) * 2e-8); // 1e-8 |x2h|^2 |m|^2 at most: |m| = |T x (R x1h)| <= |x1h| for the unit T of a fit, doubled against rounding
     if (kk == n - 1 && !(kk & 1)) { // odd count: the last record's partner is all zeros (never read as a result)
 #pragma unroll
         for (int f = 0; f < 6; f++) d[2 * f + 1] = 0.0f;
@@ -528,7 +528,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     f32x2 Ef[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) Ef[i] = splat((float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] : (i < 6 ? g.Ki[1] : 1.0))));
-    const f32x2 fmax2 = splat((float)g.Ki[3]);
     const f32x2 thr16 = splat((float)(16.0 * thr));
 
     int count = 0;
@@ -592,12 +591,13 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             // direction must be well defined (q >= 1e-6 |x1h|^2 / min(fx,fy)^2, which implies
             // |m01| >= 1e-3 |x1h|: fp32 noise in m is ~1e-7 |x1h|, and near the epipole the
             // reference's own projection is unstable), the residual must stand clear of its
-            // rounding noise (num^2 >= 1e-8 |x2h|^2 (max(fx,fy)^2 q + m2^2) >= 1e-8 |x2h|^2 |m|^2),
+            // rounding noise (num^2 >= 2e-8 |x2h|^2 |x1h|^2 >= 1e-8 |x2h|^2 |m|^2, a constant of the
+            // correspondence: |m| = |T x (R x1h)| <= |x1h| for the unit translation of a fitted pose),
             // and the observation must be an ordinary pixel (the staged guard is inf otherwise).
             // NaNs fail every test.
             // Two pairs of correspondences per iteration, their records fetched from LDS up front.
             auto test_pair = [&](int kk, const f32x2 x1, const f32x2 y1, const f32x2 u2, const f32x2 v2, const f32x2 g1,
-                                 const f32x2 r4c) __attribute__((always_inline)) {
+                                 const f32x2 g2) __attribute__((always_inline)) {
                 const f32x2 m0 = pk_fma(Ef[0], x1, pk_fma(Ef[1], y1, Ef[2]));
                 const f32x2 m1 = pk_fma(Ef[3], x1, pk_fma(Ef[4], y1, Ef[5]));
                 const f32x2 m2 = pk_fma(Ef[6], x1, pk_fma(Ef[7], y1, Ef[8]));
@@ -605,7 +605,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const f32x2 q = pk_fma(m0, m0, m1 * m1);
                 const f32x2 den2 = q * thr16;
                 const f32x2 n2 = num * num;
-                const f32x2 g2 = r4c * pk_fma(m2, m2, fmax2 * q);
                 const bool skip0 = n2.x >= den2.x && q.x >= g1.x && n2.x >= g2.x;
                 const bool skip1 = n2.y >= den2.y && q.y >= g1.y && n2.y >= g2.y;
                 // most of the time no lane of the wave has a survivor: one uniform branch around the pushes
