@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     const bool tame = fabs(r[5]) <= big && fabs(r[6]) <= big && fabs(r[7]) <= big && fabs(r[8]) <= big;
     r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
     if (!g.filter) return;
-    // fp32 record of the pre-test: x1, y1, fx x2, fy y2 (the observation in pixels off the centre),
-    // |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 |x1h|^2 * 2e-8.  Correspondences 2j and 2j + 1 of a pair
+    // fp32 record of the pre-test: x1, y1, fx x2 / c, fy y2 / c (the observation in pixels off the centre, in
+    // units of the skip distance c = 4 sqrt(maxSquaredError)), c^2 |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 |x1h|^2 * 2e-8.  Correspondences 2j and 2j + 1 of a pair
     // share twelve floats, field by field, so that one packed instruction serves both.
     int lo = 0, hi = g.nPairs; // the pair that owns correspondence k
     while (hi - lo > 1) {
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     float *d = g.rec32 + rec32_start(base, lo) + (size_t)(kk >> 1) * 12 + (kk & 1);
     d[0] = (float)r[0];
     d[2] = (float)r[1];
-    d[4] = (float)(r[2] * g.K[0]);
-    d[6] = (float)(r[3] * g.K[4]);
-    d[8] = (float)(r[9] * g.Ki[2]);
+    const double c = 4.0 * sqrt(g.maxSqErr); // the skip distance, folded into the line (see the scoring kernel)
+    d[4] = (float)(r[2] * g.K[0] / c);
+    d[6] = (float)(r[3] * g.K[4] / c);
+    d[8] = (float)(r[9] * g.Ki[2] * (c * c));
     d[10] = (float)((r[4] * r[9]) * 2e-8); // 1e-8 |x2h|^2 |m|^2 at most: |m| = |T x (R x1h)| <= |x1h| for the unit T of a fit, doubled against rounding
     if (kk == n - 1 && !(kk & 1)) { // odd count: the last record's partner is all zeros (never read as a result)
 #pragma unroll
@@ -526,9 +527,9 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     // fp32 splats for the pre-test
     // rows 0 and 1 of E divided by fx, fy: the line of a correspondence comes out in pixel metric
     f32x2 Ef[9];
+    const double skipDist = 4.0 * sqrt(thr);
 #pragma unroll
-    for (int i = 0; i < 9; i++) Ef[i] = splat((float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] : (i < 6 ? g.Ki[1] : 1.0))));
-    const f32x2 thr16 = splat((float)(16.0 * thr));
+    for (int i = 0; i < 9; i++) Ef[i] = splat((float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] * skipDist : (i < 6 ? g.Ki[1] * skipDist : 1.0))));
 
     int count = 0;
     double tot = 0.0;
@@ -582,13 +583,14 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             // triangulation picks, the point lies on the ray of x1, so its image in camera 2 lies
             // on the epipolar line of x1; the camera-2 reprojection error is therefore at least
             // the distance from the observation to that line.  With K = [fx 0 cx; 0 fy cy; 0 0 1]
-            // and m = E x1h, that distance in pixels is (x2 m0 + y2 m1 + m2) / sqrt(q),
-            // q = (m0/fx)^2 + (m1/fy)^2; the kernel works with m0/fx, m1/fy (E's rows pre-divided)
-            // and fx x2, fy y2 (staged per correspondence).  If the fp32 estimate of the distance is
-            // at least four times sqrt(maxSquaredError), the correspondence cannot be an inlier of
+            // and m = E x1h, that distance in pixels is (x2 m0 + y2 m1 + m2) / sqrt((m0/fx)^2 + (m1/fy)^2).
+            // The kernel works with c m0/fx, c m1/fy (E's rows pre-multiplied; c = four times
+            // sqrt(maxSquaredError)) and fx x2 / c, fy y2 / c (staged per correspondence), so that
+            // "distance >= c" reads num^2 >= q with q the sum of the two squares.  If the fp32 estimate
+            // says so, the correspondence cannot be an inlier of
             // this hypothesis and the exact evaluation is skipped.  Guards keep the estimate
             // within a few per cent of the truth, far inside the factor of four: the line
-            // direction must be well defined (q >= 1e-6 |x1h|^2 / min(fx,fy)^2, which implies
+            // direction must be well defined (q >= c^2 1e-6 |x1h|^2 / min(fx,fy)^2, which implies
             // |m01| >= 1e-3 |x1h|: fp32 noise in m is ~1e-7 |x1h|, and near the epipole the
             // reference's own projection is unstable), the residual must stand clear of its
             // rounding noise (num^2 >= 2e-8 |x2h|^2 |x1h|^2 >= 1e-8 |x2h|^2 |m|^2, a constant of the
@@ -603,10 +605,9 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const f32x2 m2 = pk_fma(Ef[6], x1, pk_fma(Ef[7], y1, Ef[8]));
                 const f32x2 num = pk_fma(u2, m0, pk_fma(v2, m1, m2));
                 const f32x2 q = pk_fma(m0, m0, m1 * m1);
-                const f32x2 den2 = q * thr16;
                 const f32x2 n2 = num * num;
-                const bool skip0 = n2.x >= den2.x && q.x >= g1.x && n2.x >= g2.x;
-                const bool skip1 = n2.y >= den2.y && q.y >= g1.y && n2.y >= g2.y;
+                const bool skip0 = n2.x >= q.x && q.x >= g1.x && n2.x >= g2.x;
+                const bool skip1 = n2.y >= q.y && q.y >= g1.y && n2.y >= g2.y;
                 // most of the time no lane of the wave has a survivor: one uniform branch around the pushes
                 if (!SPLIT && __builtin_amdgcn_ballot_w64(!(skip0 && skip1)) == 0) return;
                 if (kk < m) {

@@ -218,7 +218,8 @@ def test_pretest_is_off_for_unusual_intrinsics(ctx, oracle):
     assert_same_run(got, exp)
 
 
-@pytest.mark.parametrize("case", ["skew", "fx_ne_fy", "tiny_focal", "huge_focal", "tight_threshold", "negative_fx"])
+@pytest.mark.parametrize("case", ["skew", "fx_ne_fy", "tiny_focal", "huge_focal", "tight_threshold", "negative_fx",
+                                  "zero_threshold", "huge_threshold"])
 def test_pretest_with_other_intrinsics(ctx, oracle, case):
     """The pre-test works in pixel metric with fx and fy folded into the hypothesis; whatever K is, counts
     and error sums stay those of evaluating every cell."""
@@ -239,6 +240,10 @@ def test_pretest_with_other_intrinsics(ctx, oracle, case):
         thr = 1e-4
     elif case == "negative_fx":
         K[0, 0] = -K[0, 0]
+    elif case == "zero_threshold":
+        thr = 0.0
+    elif case == "huge_threshold":
+        thr = 1e30
     S = synth.sample_table(900, 256, seed=191)
     got = ctx.ransac_pair(tv["x"], tv["y"], K, S, max_sq_err=thr, adaptive=False)
     exp = oracle.ransac(tv["x"], tv["y"], K, S, max_sq_err=thr, adaptive=False)
