@@ -28,6 +28,9 @@
 #define SCORE_CH 256 // correspondences staged in LDS per step
 #define SCORE_QCAP 8 // per-lane queue of correspondences awaiting exact evaluation
 #define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
+// The pre-test skips a cell whose estimated epipolar distance is at least this many times
+// sqrt(maxSquaredError); under its guards the estimate is within 1 % of the exact distance.
+#define SKIP_FACTOR 1.25
 #define SCORE_CH32 1024 // correspondences staged per step by the instances that run the pre-test
 
 struct RansacArgs {
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
     if (!g.filter) return;
     // fp32 record of the pre-test: x1, y1, fx x2 / c, fy y2 / c (the observation in pixels off the centre, in
-    // units of the skip distance c = 4 sqrt(maxSquaredError)), c^2 |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 |x1h|^2 * 2e-8.  Correspondences 2j and 2j + 1 of a pair
+    // units of the skip distance c = SKIP_FACTOR sqrt(maxSquaredError)), c^2 |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 |x1h|^2 * 2e-8.  Correspondences 2j and 2j + 1 of a pair
     // share twelve floats, field by field, so that one packed instruction serves both.
     int lo = 0, hi = g.nPairs; // the pair that owns correspondence k
     while (hi - lo > 1) {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     float *d = g.rec32 + rec32_start(base, lo) + (size_t)(kk >> 1) * 12 + (kk & 1);
     d[0] = (float)r[0];
     d[2] = (float)r[1];
-    const double c = 4.0 * sqrt(g.maxSqErr); // the skip distance, folded into the line (see the scoring kernel)
+    const double c = SKIP_FACTOR * sqrt(g.maxSqErr); // the skip distance, folded into the line (see the scoring kernel)
     d[4] = (float)(r[2] * g.K[0] / c);
     d[6] = (float)(r[3] * g.K[4] / c);
     d[8] = (float)(r[9] * g.Ki[2] * (c * c));
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     // fp32 splats for the pre-test
     // rows 0 and 1 of E divided by fx, fy: the line of a correspondence comes out in pixel metric
     f32x2 Ef[9];
-    const double skipDist = 4.0 * sqrt(thr);
+    const double skipDist = SKIP_FACTOR * sqrt(thr);
 #pragma unroll
     for (int i = 0; i < 9; i++) Ef[i] = splat((float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] * skipDist : (i < 6 ? g.Ki[1] * skipDist : 1.0))));
 
@@ -584,12 +587,14 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             // on the epipolar line of x1; the camera-2 reprojection error is therefore at least
             // the distance from the observation to that line.  With K = [fx 0 cx; 0 fy cy; 0 0 1]
             // and m = E x1h, that distance in pixels is (x2 m0 + y2 m1 + m2) / sqrt((m0/fx)^2 + (m1/fy)^2).
-            // The kernel works with c m0/fx, c m1/fy (E's rows pre-multiplied; c = four times
+            // The kernel works with c m0/fx, c m1/fy (E's rows pre-multiplied; c = SKIP_FACTOR times
             // sqrt(maxSquaredError)) and fx x2 / c, fy y2 / c (staged per correspondence), so that
             // "distance >= c" reads num^2 >= q with q the sum of the two squares.  If the fp32 estimate
             // says so, the correspondence cannot be an inlier of
             // this hypothesis and the exact evaluation is skipped.  Guards keep the estimate
-            // within a few per cent of the truth, far inside the factor of four: the line
+            // within 1 % of the truth (line: fp32 noise 2.5e-7 |x1h| against a length of at least
+            // 1e-3 |x1h|; residual: noise below 1e-6 |x2h| |x1h| against at least 1.4e-4 |x2h| |x1h|),
+            // well inside the factor of 1.25: the line
             // direction must be well defined (q >= c^2 1e-6 |x1h|^2 / min(fx,fy)^2, which implies
             // |m01| >= 1e-3 |x1h|: fp32 noise in m is ~1e-7 |x1h|, and near the epipole the
             // reference's own projection is unstable), the residual must stand clear of its
