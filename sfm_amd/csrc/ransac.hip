@@ -12,7 +12,7 @@
 //                        broadcasts: triangulate (eightPoint.cpp:349-369, with the float cast of
 //                        :365), the two reprojection errors, count and sum inliers in index order
 //   ransac_select_kernel in-order scan with the adaptive cap (RANSAC.cpp:237-258)
-//   ransac_inlier_kernel ascending inlier list of the winner (RANSAC.cpp:213-221)
+//   ransac_inlier_*      ascending inlier list of the winner (RANSAC.cpp:213-221)
 //
 // All fp64 arithmetic below is written operation by operation (this file is compiled with
 // contraction off): same products, same sums, same order as the CPU restatement the tests
@@ -854,57 +854,90 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
 // ---------------------------------------------------------------------------------------
 // inlier list of the winner, ascending
 // ---------------------------------------------------------------------------------------
-template <bool WRITE>
-__global__ __launch_bounds__(256) void ransac_inlier_kernel(const RansacArgs g)
+// Inlier list of every pair's winner, ascending (RANSAC.cpp:213-221), in three small kernels so that a
+// pair's correspondences spread over many blocks: flags and per-block counts; per-pair totals and block
+// offsets; the indices, written from the flags without evaluating again.  grid.x blocks of 256
+// correspondences per pair (the same for every pair: the largest pair decides).
+__global__ __launch_bounds__(256) void ransac_inlier_flag_kernel(const RansacArgs g, unsigned char *__restrict__ flag,
+                                                                int *__restrict__ blkCnt)
 {
     __shared__ int waveCnt[4];
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int best = g.bestH[p];
-    if (best < 0) {
-        if (!WRITE && tid == 0) g.inlCount[p] = 0;
-        return;
-    }
     const int64_t base = g.corrOff[p];
     const int n = (int)(g.corrOff[p + 1] - base);
-    Pose P;
-    load_pose(g.pose12 + ((size_t)p * g.H + best) * 12, P);
-    double E[3][3];
-    essential_from_pose(P, E);
-    double K[9];
+    const int k = blockIdx.x * 256 + tid;
+    bool ok = false;
+    if (best >= 0 && k < n) {
+        Pose P;
+        load_pose(g.pose12 + ((size_t)p * g.H + best) * 12, P);
+        double K[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) K[i] = g.K[i];
-    int32_t *dst = WRITE ? g.inliers + g.inlOff[p] : nullptr;
-    int running = 0;
-    for (int k0 = 0; k0 < n; k0 += 256) {
-        const int k = k0 + tid;
-        bool ok = false;
-        if (k < n) {
-            const double *r = g.rec + (base + k) * REC_D;
-            double e;
-            if (g.loss == SFM_LOSS_SAMPSON)
-                e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
-            else
-                e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
-            ok = e < g.maxSqErr;
+        for (int i = 0; i < 9; i++) K[i] = g.K[i];
+        const double *r = g.rec + (base + k) * REC_D;
+        double e;
+        if (g.loss == SFM_LOSS_SAMPSON) {
+            double E[3][3];
+            essential_from_pose(P, E);
+            e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+        } else {
+            e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
         }
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
-        const int prefix = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
-        __syncthreads();
-        int off = running, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w < wave) off += waveCnt[w];
-            tot += waveCnt[w];
-        }
-        if (WRITE && ok) dst[off + prefix] = k;
-        running += tot;
-        __syncthreads();
+        ok = e < g.maxSqErr;
     }
-    if (!WRITE && tid == 0) g.inlCount[p] = running;
+    if (k < n) flag[base + k] = ok ? 1 : 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+    if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
+    __syncthreads();
+    if (tid == 0) blkCnt[(size_t)p * gridDim.x + blockIdx.x] = waveCnt[0] + waveCnt[1] + waveCnt[2] + waveCnt[3];
 }
 
-// offsets[k + 1] = sum(counts[0..k]), offsets[0] = 0; one block.
+// One block per pair: inlCount[p] and, in place of the block counts, their exclusive prefix.
+__global__ __launch_bounds__(256) void ransac_inlier_count_kernel(const RansacArgs g, int *__restrict__ blkCnt, int nBlk)
+{
+    __shared__ int part[256];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    int *cnt = blkCnt + (size_t)p * nBlk;
+    const int per = (nBlk + 255) / 256;
+    const int lo = min(nBlk, tid * per), hi = min(nBlk, lo + per);
+    int s = 0;
+    for (int b = lo; b < hi; b++) s += cnt[b];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? part[tid - 1] : 0;
+    for (int b = lo; b < hi; b++) {
+        const int c = cnt[b];
+        cnt[b] = run;
+        run += c;
+    }
+    if (tid == 255) g.inlCount[p] = part[255];
+}
+
+__global__ __launch_bounds__(256) void ransac_inlier_write_kernel(const RansacArgs g, const unsigned char *__restrict__ flag,
+                                                                 const int *__restrict__ blkOff)
+{
+    __shared__ int waveCnt[4];
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    const int k = blockIdx.x * 256 + tid;
+    if (blockIdx.x * 256 >= n) return;
+    const bool ok = k < n && flag[base + k] != 0;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+    const int prefix = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
+    __syncthreads();
+    int off = blkOff[(size_t)p * gridDim.x + blockIdx.x];
+    for (int w = 0; w < wave; w++) off += waveCnt[w];
+    if (ok) g.inliers[g.inlOff[p] + off + prefix] = k;
+}
+
 __global__ __launch_bounds__(1024) void ransac_scan_kernel(const int *__restrict__ counts, int n,
                                                            int64_t *__restrict__ offsets)
 {
@@ -1165,7 +1198,7 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, inlFlag, inlBlk;
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
@@ -1179,7 +1212,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
-                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32};
+                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->inlFlag, &b->inlBlk};
     for (DevBuf *d : bufs) d->release();
     delete b;
 }
@@ -1380,9 +1413,18 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         hipLaunchKernelGGL(ransac_select_kernel, dim3(n_pairs), dim3(256), 0, st, g);
     }
     if (!fit_only) {
-        hipLaunchKernelGGL((ransac_inlier_kernel<false>), dim3(n_pairs), dim3(256), 0, st, g);
+        int64_t maxN = 0;
+        for (int p = 0; p < n_pairs; p++) maxN = std::max(maxN, corr_offsets[p + 1] - corr_offsets[p]);
+        const int nBlk = (int)std::max<int64_t>(1, (maxN + 255) / 256);
+        SFM_HIP(ctx, b->inlFlag.reserve((size_t)(total ? total : 1)));
+        SFM_HIP(ctx, b->inlBlk.reserve((size_t)n_pairs * nBlk * sizeof(int)));
+        unsigned char *flag = b->inlFlag.as<unsigned char>();
+        int *blk = b->inlBlk.as<int>();
+        hipLaunchKernelGGL(ransac_inlier_flag_kernel, dim3(nBlk, n_pairs), dim3(256), 0, st, g, flag, blk);
+        hipLaunchKernelGGL(ransac_inlier_count_kernel, dim3(n_pairs), dim3(256), 0, st, g, blk, nBlk);
         hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(1024), 0, st, g.inlCount, n_pairs, b->inlOff.as<int64_t>());
-        hipLaunchKernelGGL((ransac_inlier_kernel<true>), dim3(n_pairs), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(ransac_inlier_write_kernel, dim3(nBlk, n_pairs), dim3(256), 0, st, g, (const unsigned char *)flag,
+                           (const int *)blk);
     }
     SFM_HIP(ctx, hipGetLastError());
     b->args = g;
