@@ -611,10 +611,15 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const f32x2 num = pk_fma(u2, m0, pk_fma(v2, m1, m2));
                 const f32x2 q = pk_fma(m0, m0, m1 * m1);
                 const f32x2 n2 = num * num;
-                const bool skip0 = n2.x >= q.x && q.x >= g1.x && n2.x >= g2.x;
-                const bool skip1 = n2.y >= q.y && q.y >= g1.y && n2.y >= g2.y;
-                // most of the time no lane of the wave has a survivor: one uniform branch around the pushes
-                if (!SPLIT && __builtin_amdgcn_ballot_w64(!(skip0 && skip1)) == 0) return;
+                // The comparisons deliver lane masks; they are combined in scalar registers, and most of the
+                // time no lane of the wave has a survivor: one uniform branch around the pushes.
+                constexpr int OGE = 3; // ordered >=: false on NaN
+                const unsigned long long skipMask0 = __builtin_amdgcn_fcmpf(n2.x, q.x, OGE) & __builtin_amdgcn_fcmpf(q.x, g1.x, OGE) &
+                                                     __builtin_amdgcn_fcmpf(n2.x, g2.x, OGE);
+                const unsigned long long skipMask1 = __builtin_amdgcn_fcmpf(n2.y, q.y, OGE) & __builtin_amdgcn_fcmpf(q.y, g1.y, OGE) &
+                                                     __builtin_amdgcn_fcmpf(n2.y, g2.y, OGE);
+                if (!SPLIT && (skipMask0 & skipMask1) == __builtin_amdgcn_ballot_w64(true)) return;
+                const bool skip0 = (skipMask0 >> (tid & 63)) & 1ull, skip1 = (skipMask1 >> (tid & 63)) & 1ull;
                 if (kk < m) {
                     if (!skip0) pend[npend++][tid] = (unsigned short)kk;
                     else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
