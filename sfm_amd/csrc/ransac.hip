@@ -39,7 +39,7 @@ struct RansacArgs {
     const int64_t *corrOff; // [P+1], device
     const int32_t *samples; // [P][H][8]
     double *rec;            // [total][REC_D]
-    float *rec32;           // pre-test records in fp32, pairs of correspondences interleaved (see rec32_start)
+    float *rec32;           // pre-test records in fp32, four correspondences interleaved (see rec32_start)
     double *pose12;         // [P][H][12] R row-major then T
     int *counts;            // [P][H]
     double *toterr;         // [P][H]
@@ -51,7 +51,7 @@ struct RansacArgs {
     const int64_t *inlOff;  // [P+1]
     int32_t *inliers;
     double K[9]; // column-major
-    double Ki[4]; // pre-test constants (valid when filter != 0): 1/fx, 1/fy, 1e-6/min(fx,fy)^2, max(fx,fy)^2
+    double Ki[4]; // pre-test constants (valid when filter != 0): 1/fx, 1/fy, 1/min(fx,fy), max(fx,fy)^2
     int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
     double maxSqErr;
     double successProb;
@@ -157,9 +157,9 @@ __device__ __forceinline__ double sampson_loss(const double *K, const double E[3
 // ---------------------------------------------------------------------------------------
 // prep
 // ---------------------------------------------------------------------------------------
-// First float of pair p's pre-test records (its correspondences start at row `base`): a multiple of 12,
-// and regions of consecutive pairs do not overlap (each takes 12 * ceil(n / 2) floats).
-__host__ __device__ inline size_t rec32_start(int64_t base, int p) { return (size_t)12 * (size_t)((base + p + 1) / 2); }
+// First float of pair p's pre-test records (its correspondences start at row `base`): a multiple of 20,
+// and regions of consecutive pairs do not overlap (each takes 20 * ceil(n / 4) floats).
+__host__ __device__ inline size_t rec32_start(int64_t base, int p) { return (size_t)20 * (size_t)((base + 3 * (int64_t)p + 3) / 4); }
 
 __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, int64_t total)
 {
@@ -182,8 +182,9 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
     if (!g.filter) return;
     // fp32 record of the pre-test: x1, y1, fx x2 / c, fy y2 / c (the observation in pixels off the centre, in
-    // units of the skip distance c = SKIP_FACTOR sqrt(maxSquaredError)), c^2 |x1h|^2 * 1e-6 / min(fx,fy)^2 (or inf), |x2h|^2 |x1h|^2 * 2e-8.  Correspondences 2j and 2j + 1 of a pair
-    // share twelve floats, field by field, so that one packed instruction serves both.
+    // units of the skip distance c = SKIP_FACTOR sqrt(maxSquaredError)) and the margin G that pays for the
+    // rounding of the fp32 estimate (derived in the scoring kernel), or inf.  Correspondences 4j .. 4j + 3 of a
+    // pair share twenty floats, field by field, so that one packed instruction serves two of them.
     int lo = 0, hi = g.nPairs; // the pair that owns correspondence k
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -192,18 +193,19 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     const int64_t base = g.corrOff[lo];
     const int kk = (int)(k - base);
     const int n = (int)(g.corrOff[lo + 1] - base);
-    float *d = g.rec32 + rec32_start(base, lo) + (size_t)(kk >> 1) * 12 + (kk & 1);
-    d[0] = (float)r[0];
-    d[2] = (float)r[1];
+    float *d = g.rec32 + rec32_start(base, lo) + (size_t)(kk >> 2) * 20 + (kk & 3);
     const double c = SKIP_FACTOR * sqrt(g.maxSqErr); // the skip distance, folded into the line (see the scoring kernel)
-    d[4] = (float)(r[2] * g.K[0] / c);
-    d[6] = (float)(r[3] * g.K[4] / c);
-    d[8] = (float)(r[9] * g.Ki[2] * (c * c));
-    d[10] = (float)((r[4] * r[9]) * 2e-8); // 1e-8 |x2h|^2 |m|^2 at most: |m| = |T x (R x1h)| <= |x1h| for the unit T of a fit, doubled against rounding
-    if (kk == n - 1 && !(kk & 1)) { // odd count: the last record's partner is all zeros (never read as a result)
+    d[0] = (float)r[0];
+    d[4] = (float)r[1];
+    d[8] = (float)(r[2] * g.K[0] / c);
+    d[12] = (float)(r[3] * g.K[4] / c);
+    const double x1n = sqrt(r[9]), x2n = sqrt(r[4]);
+    const double D = (1e-6 * c * g.Ki[2]) * x1n + 2e-6 * (x2n * x1n); // Ki[2] = 1 / min(fx, fy)
+    d[16] = tame ? (float)fmax(70.0 * (D * D), 1e-30) : INFINITY;       // (kept clear of the denormals)
+    if (kk == n - 1) // the rest of the last group is never read as a result
+        for (int f = (kk & 3) + 1; f < 4; f++)
 #pragma unroll
-        for (int f = 0; f < 6; f++) d[2 * f + 1] = 0.0f;
-    }
+            for (int e = 0; e < 5; e++) d[4 * e + f - (kk & 3)] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -490,7 +492,7 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 // errBuf[(correspondence, row)]: the error of an inlier, a negative NaN pattern otherwise, and
 // ransac_sum_kernel adds the inliers' errors up in order.
 // FILTER: the instance that runs the pre-test (reprojection loss, plain intrinsics).  It stages only the
-// fp32 records (24 B per correspondence, SCORE_CH32 at a time, prepared once by ransac_prep_kernel) and
+// fp32 records (20 B per correspondence, SCORE_CH32 at a time, prepared once by ransac_prep_kernel) and
 // fetches the fp64 record of the rare survivor from global memory; the other instances evaluate every
 // cell and stage the fp64 records.
 template <int LOSS, bool SPLIT, bool FILTER>
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
     __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
     __shared__ unsigned short pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of chunk-local correspondence indices
-    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 2 + 1) * 12 : 4];
+    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 4) * 20 : 4];
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
     const int h = g.hBegin + blockIdx.x * 256 + tid;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     const bool active = h < g.hEnd;
     int kBeg = 0, kEnd = n;
     if (SPLIT) {
-        const int seg = (((n + (int)gridDim.z - 1) / (int)gridDim.z) + 1) & ~1;
+        const int seg = (((n + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3; // whole groups of the fp32 records
         kBeg = min(n, (int)blockIdx.z * seg);
         kEnd = min(n, kBeg + seg);
         if (kBeg >= kEnd) return;
@@ -565,9 +567,9 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     for (int k0 = kBeg; k0 < kEnd; k0 += CH) {
         const int m = min(CH, kEnd - k0);
         kChunk = k0;
-        if (FILTER) { // k0 is even: whole twelve-float groups
-            const uint4 *src = reinterpret_cast<const uint4 *>(rec32g + (size_t)(k0 >> 1) * 12);
-            for (int q = tid; q < ((m + 1) >> 1) * 3; q += 256) reinterpret_cast<uint4 *>(rec32)[q] = src[q];
+        if (FILTER) { // k0 is a multiple of four: whole twenty-float groups
+            const uint4 *src = reinterpret_cast<const uint4 *>(rec32g + (size_t)(k0 >> 2) * 20);
+            for (int q = tid; q < ((m + 3) >> 2) * 5; q += 256) reinterpret_cast<uint4 *>(rec32)[q] = src[q];
         } else {
             const double2 *src = reinterpret_cast<const double2 *>(g.rec + (base + k0) * REC_D);
             for (int q = tid; q < m * (REC_D / 2); q += 256) reinterpret_cast<double2 *>(rec)[q] = src[q];
@@ -586,38 +588,37 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             // triangulation picks, the point lies on the ray of x1, so its image in camera 2 lies
             // on the epipolar line of x1; the camera-2 reprojection error is therefore at least
             // the distance from the observation to that line.  With K = [fx 0 cx; 0 fy cy; 0 0 1]
-            // and m = E x1h, that distance in pixels is (x2 m0 + y2 m1 + m2) / sqrt((m0/fx)^2 + (m1/fy)^2).
-            // The kernel works with c m0/fx, c m1/fy (E's rows pre-multiplied; c = SKIP_FACTOR times
-            // sqrt(maxSquaredError)) and fx x2 / c, fy y2 / c (staged per correspondence), so that
-            // "distance >= c" reads num^2 >= q with q the sum of the two squares.  If the fp32 estimate
-            // says so, the correspondence cannot be an inlier of
-            // this hypothesis and the exact evaluation is skipped.  Guards keep the estimate
-            // within 1 % of the truth (line: fp32 noise 2.5e-7 |x1h| against a length of at least
-            // 1e-3 |x1h|; residual: noise below 1e-6 |x2h| |x1h| against at least 1.4e-4 |x2h| |x1h|),
-            // well inside the factor of 1.25: the line
-            // direction must be well defined (q >= c^2 1e-6 |x1h|^2 / min(fx,fy)^2, which implies
-            // |m01| >= 1e-3 |x1h|: fp32 noise in m is ~1e-7 |x1h|, and near the epipole the
-            // reference's own projection is unstable), the residual must stand clear of its
-            // rounding noise (num^2 >= 2e-8 |x2h|^2 |x1h|^2 >= 1e-8 |x2h|^2 |m|^2, a constant of the
-            // correspondence: |m| = |T x (R x1h)| <= |x1h| for the unit translation of a fitted pose),
-            // and the observation must be an ordinary pixel (the staged guard is inf otherwise).
-            // NaNs fail every test.
+            // and m = E x1h, that distance in pixels is |x2 m0 + y2 m1 + m2| / sqrt((m0/fx)^2 + (m1/fy)^2).
+            // The kernel works with M0 = c m0/fx, M1 = c m1/fy (E's rows pre-multiplied; c = SKIP_FACTOR
+            // times sqrt(maxSquaredError)) and fx x2 / c, fy y2 / c (staged per correspondence), so that
+            // "distance >= c" reads num^2 >= q with num = x2h.m and q = M0^2 + M1^2.
+            // One comparison decides, with the rounding of the fp32 estimate priced in: the exact
+            // values satisfy |num*| >= |num| - e and sqrt(q*) <= sqrt(q) + d, where
+            //   d <= 3.4e-7 c |x1h| / min(fx,fy)   (four roundings of 6e-8 on each term of M0, M1; the rows of
+            //                                       E = [T]x R have norm <= 1 for the unit translation of a fitted pose)
+            //   e <= 6e-7 |x2h| |x1h|              (the same on num: |x2h.m| <= |x2h| |x1h|),
+            // and (a + D)^2 <= (1 + h) a^2 + (1 + 1/h) D^2 for any h > 0.  With h = 0.015 and D = d + e,
+            //   num^2 >= 1.02 q + 70 D^2
+            // implies |num*| >= sqrt(q*), the other 0.005 paying for the roundings of q, num^2 and the staged
+            // constant.  The staged G is 70 D^2 with d, e three times the bounds above, and the factor
+            // 1.02 is part of SKIP_FACTOR: a correspondence that passes lies at least
+            // SKIP_FACTOR / sqrt(1.02) sqrt(maxSquaredError) from the line, cannot be an inlier of this
+            // hypothesis, and its exact evaluation is skipped.  G is inf for an observation that is not an
+            // ordinary pixel; NaNs fail the test.
             // Two pairs of correspondences per iteration, their records fetched from LDS up front.
-            auto test_pair = [&](int kk, const f32x2 x1, const f32x2 y1, const f32x2 u2, const f32x2 v2, const f32x2 g1,
-                                 const f32x2 g2) __attribute__((always_inline)) {
+            auto test_pair = [&](int kk, const f32x2 x1, const f32x2 y1, const f32x2 u2, const f32x2 v2, const f32x2 gg)
+                                 __attribute__((always_inline)) {
                 const f32x2 m0 = pk_fma(Ef[0], x1, pk_fma(Ef[1], y1, Ef[2]));
                 const f32x2 m1 = pk_fma(Ef[3], x1, pk_fma(Ef[4], y1, Ef[5]));
                 const f32x2 m2 = pk_fma(Ef[6], x1, pk_fma(Ef[7], y1, Ef[8]));
                 const f32x2 num = pk_fma(u2, m0, pk_fma(v2, m1, m2));
-                const f32x2 q = pk_fma(m0, m0, m1 * m1);
+                const f32x2 q = pk_fma(m0, m0, pk_fma(m1, m1, gg));
                 const f32x2 n2 = num * num;
                 // The comparisons deliver lane masks; they are combined in scalar registers, and most of the
                 // time no lane of the wave has a survivor: one uniform branch around the pushes.
                 constexpr int OGE = 3; // ordered >=: false on NaN
-                const unsigned long long skipMask0 = __builtin_amdgcn_fcmpf(n2.x, q.x, OGE) & __builtin_amdgcn_fcmpf(q.x, g1.x, OGE) &
-                                                     __builtin_amdgcn_fcmpf(n2.x, g2.x, OGE);
-                const unsigned long long skipMask1 = __builtin_amdgcn_fcmpf(n2.y, q.y, OGE) & __builtin_amdgcn_fcmpf(q.y, g1.y, OGE) &
-                                                     __builtin_amdgcn_fcmpf(n2.y, g2.y, OGE);
+                const unsigned long long skipMask0 = __builtin_amdgcn_fcmpf(n2.x, q.x, OGE);
+                const unsigned long long skipMask1 = __builtin_amdgcn_fcmpf(n2.y, q.y, OGE);
                 if (!SPLIT && (skipMask0 & skipMask1) == __builtin_amdgcn_ballot_w64(true)) return;
                 const bool skip0 = (skipMask0 >> (tid & 63)) & 1ull, skip1 = (skipMask1 >> (tid & 63)) & 1ull;
                 if (kk < m) {
@@ -630,13 +631,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 }
             };
             for (int kk = 0; kk < m; kk += 4) {
-                // (a chunk holds an even number of twelve-float groups' worth of LDS: reading one group
-                // past the last is harmless, its results are discarded by the kk < m tests)
-                const f32x2 *rp = reinterpret_cast<const f32x2 *>(rec32 + (kk >> 1) * 12);
-                const f32x2 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3], a4 = rp[4], a5 = rp[5];
-                const f32x2 b0 = rp[6], b1 = rp[7], b2 = rp[8], b3 = rp[9], b4 = rp[10], b5 = rp[11];
-                test_pair(kk, a0, a1, a2, a3, a4, a5);
-                test_pair(kk + 2, b0, b1, b2, b3, b4, b5);
+                // (the last group of a pair is padded: results past m are discarded by the kk < m tests)
+                const float4 *rp = reinterpret_cast<const float4 *>(rec32 + (kk >> 2) * 20);
+                const float4 X = rp[0], Y = rp[1], U = rp[2], V = rp[3], G = rp[4];
+                test_pair(kk, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{U.x, U.y}, f32x2{V.x, V.y}, f32x2{G.x, G.y});
+                test_pair(kk + 2, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{U.z, U.w}, f32x2{V.z, V.w}, f32x2{G.z, G.w});
                 // room for the next four: drain as soon as any lane of the wave holds more than four
                 if (__builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 4) != 0) drain();
             }
@@ -1303,7 +1302,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     }
     SFM_HIP(ctx, b->corrOff.reserve((P1 + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, b->rec.reserve((size_t)(total ? total : 1) * REC_D * sizeof(double)));
-    SFM_HIP(ctx, b->rec32.reserve((rec32_start(total, n_pairs) + 24) * sizeof(float)));
+    SFM_HIP(ctx, b->rec32.reserve((rec32_start(total, n_pairs) + 40) * sizeof(float)));
     SFM_HIP(ctx, b->pose12.reserve(PH * 12 * sizeof(double)));
     SFM_HIP(ctx, b->counts.reserve(PH * sizeof(int)));
     SFM_HIP(ctx, b->toterr.reserve(PH * sizeof(double)));
@@ -1344,7 +1343,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         g.filter = ok ? 1 : 0;
         g.Ki[0] = ok ? 1.0 / fx : 0.0;
         g.Ki[1] = ok ? 1.0 / fy : 0.0;
-        g.Ki[2] = ok ? 1e-6 / (std::min(fx, fy) * std::min(fx, fy)) : 0.0; // guard on the line direction
+        g.Ki[2] = ok ? 1.0 / std::min(fx, fy) : 0.0;
         g.Ki[3] = ok ? std::max(fx, fy) * std::max(fx, fy) : 0.0;          // bound of |m|^2 from the scaled line
     }
     g.maxSqErr = maxSqErr;
