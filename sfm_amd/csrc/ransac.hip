@@ -28,9 +28,10 @@
 #define SCORE_CH 256 // correspondences staged in LDS per step
 #define SCORE_QCAP 8 // per-lane queue of correspondences awaiting exact evaluation
 #define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
-// The pre-test skips a cell whose estimated epipolar distance is at least this many times
-// sqrt(maxSquaredError); under its guards the estimate is within 1 % of the exact distance.
-#define SKIP_FACTOR 1.25
+// The pre-test skips a cell whose estimated epipolar distance, less the margin that pays for the fp32
+// rounding, is at least this many times sqrt(maxSquaredError); a factor of sqrt(1.02) of it belongs to
+// that margin (see the scoring kernel), which leaves 1.052.
+#define SKIP_FACTOR 1.0625
 #define SCORE_CH32 1024 // correspondences staged per step by the instances that run the pre-test
 
 struct RansacArgs {
