@@ -35,3 +35,7 @@ late = t0 - base > 10000
 print("blocks starting later than 100 us:", int(late.sum()))
 np.save("gpurun_out/score_blocks.npy", buf)
 ctx.close()
+wave = hwid & 0xF; simd = (hwid >> 4) & 3
+print("wave slots used by thread 0's wave:", np.bincount(wave), "simd", np.bincount(simd))
+for w in np.unique(wave):
+    print("  slot", w, "mean dur", dur[wave == w].mean())

@@ -565,9 +565,25 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
         npend = 0;
     };
     const float *rec32g = FILTER ? g.rec32 + rec32_start(base, p) : nullptr;
+    // The instruction arbiter of a SIMD favours its oldest wave: of the four blocks a CU holds, which all start
+    // together and have the same work, the first would finish a third ahead of the last, and the stragglers
+    // cannot fill the vector ALU on their own.  Each wave therefore moves its priority round from chunk to
+    // chunk, starting from its slot on the SIMD, so that every wave leads a quarter of the time and all
+    // finish together.
+    unsigned hwId = 0;
+    if (FILTER && !SPLIT) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
+    unsigned turn = hwId & 3; // wave slot on the SIMD
     for (int k0 = kBeg; k0 < kEnd; k0 += CH) {
         const int m = min(CH, kEnd - k0);
         kChunk = k0;
+        if (FILTER && !SPLIT) {
+            switch (turn++ & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         if (FILTER) { // k0 is a multiple of four: whole twenty-float groups
             const uint4 *src = reinterpret_cast<const uint4 *>(rec32g + (size_t)(k0 >> 2) * 20);
             for (int q = tid; q < ((m + 3) >> 2) * 5; q += 256) reinterpret_cast<uint4 *>(rec32)[q] = src[q];
