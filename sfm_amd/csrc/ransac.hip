@@ -646,6 +646,8 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                     if (!skip1) pend[npend++][tid] = (unsigned short)(kk + 1);
                     else if (SPLIT && active) errCol[(size_t)(kChunk + kk + 1) * rows] = none;
                 }
+                // room for the next two: drain as soon as any lane of the wave holds more than six
+                if (__builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 2) != 0) drain();
             };
             for (int kk = 0; kk < m; kk += 4) {
                 // (the last group of a pair is padded: results past m are discarded by the kk < m tests)
@@ -653,8 +655,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 const float4 X = rp[0], Y = rp[1], U = rp[2], V = rp[3], G = rp[4];
                 test_pair(kk, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{U.x, U.y}, f32x2{V.x, V.y}, f32x2{G.x, G.y});
                 test_pair(kk + 2, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{U.z, U.w}, f32x2{V.z, V.w}, f32x2{G.z, G.w});
-                // room for the next four: drain as soon as any lane of the wave holds more than four
-                if (__builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 4) != 0) drain();
             }
             drain(); // the queue indexes this chunk's records
         }
