@@ -26,7 +26,7 @@
 #pragma clang fp contract(off)
 
 #define SCORE_CH 256 // correspondences staged in LDS per step
-#define SCORE_QCAP 8 // per-lane queue of correspondences awaiting exact evaluation
+#define SCORE_QCAP 16 // per-lane queue of correspondences awaiting exact evaluation
 #define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
 // The pre-test skips a cell whose estimated epipolar distance, less the margin that pays for the fp32
 // rounding, is at least this many times sqrt(maxSquaredError); a factor of sqrt(1.02) of it belongs to
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     static_assert(!FILTER || LOSS != SFM_LOSS_SAMPSON, "the pre-test bounds the reprojection error");
     constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
     __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
-    __shared__ unsigned short pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of chunk-local correspondence indices
+    __shared__ unsigned int pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of correspondence indices (relative to the pair)
     __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 4) * 20 : 4];
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
@@ -555,8 +555,10 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             tot += e;
         }
     };
+    // (the pre-test instance queues indices relative to the pair, kChunk staying 0 for record(), and reads
+    // the fp64 record from global memory; the others index the chunk staged in LDS)
     auto evaluate = [&](int kk) {
-        const double *r = FILTER ? g.rec + (size_t)(base + kChunk + kk) * REC_D : rec + kk * REC_D;
+        const double *r = FILTER ? g.rec + (size_t)(base + kk) * REC_D : rec + kk * REC_D;
         record(kk, reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]));
     };
     auto drain = [&]() {
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     unsigned turn = hwId & 3; // wave slot on the SIMD
     for (int k0 = kBeg; k0 < kEnd; k0 += CH) {
         const int m = min(CH, kEnd - k0);
-        kChunk = k0;
+        kChunk = FILTER ? 0 : k0;
         if (FILTER && !SPLIT) {
             switch (turn++ & 3) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -639,12 +641,12 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 if (!SPLIT && (skipMask0 & skipMask1) == __builtin_amdgcn_ballot_w64(true)) return;
                 const bool skip0 = (skipMask0 >> (tid & 63)) & 1ull, skip1 = (skipMask1 >> (tid & 63)) & 1ull;
                 if (kk < m) {
-                    if (!skip0) pend[npend++][tid] = (unsigned short)kk;
-                    else if (SPLIT && active) errCol[(size_t)(kChunk + kk) * rows] = none;
+                    if (!skip0) pend[npend++][tid] = (unsigned)(k0 + kk);
+                    else if (SPLIT && active) errCol[(size_t)(k0 + kk) * rows] = none;
                 }
                 if (kk + 1 < m) {
-                    if (!skip1) pend[npend++][tid] = (unsigned short)(kk + 1);
-                    else if (SPLIT && active) errCol[(size_t)(kChunk + kk + 1) * rows] = none;
+                    if (!skip1) pend[npend++][tid] = (unsigned)(k0 + kk + 1);
+                    else if (SPLIT && active) errCol[(size_t)(k0 + kk + 1) * rows] = none;
                 }
                 // room for the next two: drain as soon as any lane of the wave holds more than six
                 if (__builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 2) != 0) drain();
@@ -656,10 +658,10 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 test_pair(kk, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{U.x, U.y}, f32x2{V.x, V.y}, f32x2{G.x, G.y});
                 test_pair(kk + 2, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{U.z, U.w}, f32x2{V.z, V.w}, f32x2{G.z, G.w});
             }
-            drain(); // the queue indexes this chunk's records
         }
         __syncthreads();
     }
+    if (FILTER) drain(); // what the last pushes left
     if (active && !SPLIT) {
         g.counts[(size_t)p * g.H + h] = count;
         g.toterr[(size_t)p * g.H + h] = tot;
