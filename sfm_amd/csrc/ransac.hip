@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
     __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
     __shared__ unsigned int pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of correspondence indices (relative to the pair)
-    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 4) * 20 : 4];
+    __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 4 + 2) * 20 : 4]; // + 2: the pipeline reads ahead
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
     const int h = g.hBegin + blockIdx.x * 256 + tid;
@@ -651,12 +651,25 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 // room for the next two: drain as soon as any lane of the wave holds more than six
                 if (__builtin_amdgcn_ballot_w64(npend > SCORE_QCAP - 2) != 0) drain();
             };
-            for (int kk = 0; kk < m; kk += 4) {
-                // (the last group of a pair is padded: results past m are discarded by the kk < m tests)
+            // Software pipeline over two register sets: the next four records are on their way from LDS
+            // while the current four are tested.  (Groups past the chunk's last hold stale or padded values:
+            // their results are discarded by the kk < m tests.)
+            auto load4 = [&](int kk, float4(&r)[5]) __attribute__((always_inline)) {
                 const float4 *rp = reinterpret_cast<const float4 *>(rec32 + (kk >> 2) * 20);
-                const float4 X = rp[0], Y = rp[1], U = rp[2], V = rp[3], G = rp[4];
-                test_pair(kk, f32x2{X.x, X.y}, f32x2{Y.x, Y.y}, f32x2{U.x, U.y}, f32x2{V.x, V.y}, f32x2{G.x, G.y});
-                test_pair(kk + 2, f32x2{X.z, X.w}, f32x2{Y.z, Y.w}, f32x2{U.z, U.w}, f32x2{V.z, V.w}, f32x2{G.z, G.w});
+#pragma unroll
+                for (int i = 0; i < 5; i++) r[i] = rp[i];
+            };
+            auto test4 = [&](int kk, const float4(&r)[5]) __attribute__((always_inline)) {
+                test_pair(kk, f32x2{r[0].x, r[0].y}, f32x2{r[1].x, r[1].y}, f32x2{r[2].x, r[2].y}, f32x2{r[3].x, r[3].y}, f32x2{r[4].x, r[4].y});
+                test_pair(kk + 2, f32x2{r[0].z, r[0].w}, f32x2{r[1].z, r[1].w}, f32x2{r[2].z, r[2].w}, f32x2{r[3].z, r[3].w}, f32x2{r[4].z, r[4].w});
+            };
+            float4 ra[5], rb[5];
+            load4(0, ra);
+            for (int kk = 0; kk < m; kk += 8) {
+                load4(kk + 4, rb);
+                test4(kk, ra);
+                load4(kk + 8, ra);
+                test4(kk + 4, rb);
             }
         }
         __syncthreads();
