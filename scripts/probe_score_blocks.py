@@ -1,4 +1,5 @@
-"""Per-block start/end times of the unsplit score kernel (library built with -DSFM_DEBUG_TIMES)."""
+"""Per-block start/end times of the unsplit score kernel.  Needs a measurement build of the library:
+(cd sfm_amd/csrc && touch ransac.hip && make EXTRA=-DSFM_DEBUG_TIMES); rebuild without EXTRA afterwards."""
 import argparse, ctypes as C, json, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -14,8 +15,8 @@ print(out["value"], out["score_kernel_ms_per_step"])
 L = capi.lib()
 n = 1024
 buf = np.zeros(3 * n, dtype=np.uint64)
-L.sfm_debug_dump.argtypes = [C.c_void_p, C.c_int]
-rc = L.sfm_debug_dump(buf.ctypes.data, 3 * n)
+L.sfm_debug_score_times.argtypes = [C.c_void_p, C.c_int]
+rc = L.sfm_debug_score_times(buf.ctypes.data, 3 * n)
 t0 = buf[0::3].astype(np.int64); t1 = buf[1::3].astype(np.int64); hw = buf[2::3]
 base = t0.min()
 dur = (t1 - t0) / 100.0  # us at 100 MHz

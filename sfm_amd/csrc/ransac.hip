@@ -496,9 +496,16 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 // fp32 records (20 B per correspondence, SCORE_CH32 at a time, prepared once by ransac_prep_kernel) and
 // fetches the fp64 record of the rare survivor from global memory; the other instances evaluate every
 // cell and stage the fp64 records.
+#ifdef SFM_DEBUG_TIMES // measurement build only (make EXTRA=-DSFM_DEBUG_TIMES): start, end and placement of every block
+__device__ unsigned long long g_scoreTimes[3 * 8192];
+extern "C" int sfm_debug_score_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scoreTimes), n * 8); }
+#endif
 template <int LOSS, bool SPLIT, bool FILTER>
 __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, double *__restrict__ errBuf)
 {
+#ifdef SFM_DEBUG_TIMES
+    const unsigned long long dbgT0 = wall_clock64();
+#endif
     static_assert(!FILTER || LOSS != SFM_LOSS_SAMPSON, "the pre-test bounds the reprojection error");
     constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
     __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
@@ -679,6 +686,17 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
         g.counts[(size_t)p * g.H + h] = count;
         g.toterr[(size_t)p * g.H + h] = tot;
     }
+#ifdef SFM_DEBUG_TIMES
+    if (tid == 0 && !SPLIT) {
+        const int b = (blockIdx.y * gridDim.x + blockIdx.x) & 8191;
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_scoreTimes[3 * b] = dbgT0;
+        g_scoreTimes[3 * b + 1] = wall_clock64();
+        g_scoreTimes[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 // Second half of a split scoring launch: every row adds up its inliers' errors in correspondence
