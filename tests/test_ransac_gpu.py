@@ -208,6 +208,42 @@ def test_pretest_never_changes_a_result(ctx, oracle):
         assert np.array_equal(res[0]["counts"], exp["counts"]) and np.array_equal(res[0]["inliers"], exp["inliers"])
 
 
+@pytest.mark.parametrize("thr", [1.0, 25.0, 1e-2])
+def test_pretest_at_the_skip_boundary(ctx, oracle, thr):
+    """Observations displaced from their epipolar line by 0.8 ... 1.3 times sqrt(maxSquaredError), under
+    hypotheses fitted to noise-free samples (so nearly the planted pose): the cells right at the threshold and
+    right at the skip distance.  Counts, error sums and inliers with the pre-test on are those with it off
+    and those of the CPU restatement."""
+    n = 2400
+    tv = synth.two_view(n, inlier_ratio=1.0, seed=301, noise_px=0.0)
+    x, y, K = tv["x"].copy(), tv["y"].copy(), tv["K"]
+    R, T = tv["R"], tv["T"]
+    Tx = np.array([[0, -T[2], T[1]], [T[2], 0, -T[0]], [-T[1], T[0], 0]])
+    E = Tx @ R
+    fx, fy = K[0, 0], K[1, 1]
+    x1h = np.concatenate([x, np.ones((n, 1))], axis=1)
+    m = x1h @ E.T  # epipolar lines in normalised camera-2 coordinates
+    # unit normal of the line in pixels, mapped back to normalised coordinates
+    npx = np.stack([m[:, 0] / fx, m[:, 1] / fy], axis=1)
+    npx /= np.linalg.norm(npx, axis=1, keepdims=True)
+    d = np.linspace(0.8, 1.3, n - 400) * np.sqrt(thr) * np.where(np.arange(n - 400) % 2, 1.0, -1.0)
+    y[400:, 0] += d * npx[400:, 0] / fx
+    y[400:, 1] += d * npx[400:, 1] / fy
+    S = synth.sample_table(400, 256, seed=302)  # samples among the untouched correspondences only
+    res = []
+    for flt in (1, 0):
+        ctx.set_option("ransac_filter", flt)
+        res.append(ctx.ransac_pair(x, y, K, S, max_sq_err=thr, adaptive=False))
+    ctx.set_option("ransac_filter", 1)
+    assert np.array_equal(res[0]["counts"], res[1]["counts"])
+    assert np.array_equal(res[0]["toterr"].view(np.uint64), res[1]["toterr"].view(np.uint64))
+    assert np.array_equal(res[0]["inliers"], res[1]["inliers"])
+    exp = oracle.ransac(x, y, K, S, max_sq_err=thr, adaptive=False)
+    assert np.array_equal(res[0]["counts"], exp["counts"]) and np.array_equal(res[0]["inliers"], exp["inliers"])
+    # the band straddles the threshold: some displaced observations are inliers of the best row, most are not
+    assert 400 < res[0]["counts"].max() < n
+
+
 def test_pretest_is_off_for_unusual_intrinsics(ctx, oracle):
     tv = synth.two_view(600, inlier_ratio=0.5, seed=93)
     K = tv["K"].copy()
