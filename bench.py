@@ -73,6 +73,8 @@ def main():
     ctx = capi.Context(local_rank)
     sim_variant, bound_dtype, bound_peak = BOUNDS[args.bound]
     ctx.set_option("sim_variant", sim_variant)
+    if "SFM_MATCH_OVERLAP" in os.environ:  # A/B switch of the matcher's two-stream chunk overlap
+        ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
     if args.first_slice > 0:
         ctx.set_option("hyps_per_launch", args.first_slice)
 

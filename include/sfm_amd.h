@@ -77,7 +77,12 @@ const char *sfm_version(void);
  * scale chain's (step, track) table, default 2^26; a sequence that needs more
  * goes through in windows of steps; results are identical), "hamming_mfma"
  * (1 = 256-bit binary descriptors are first matched on the matrix cores as
- * sign vectors, default; 0 = popcount kernel only; results are identical).
+ * sign vectors, default; 0 = popcount kernel only; results are identical),
+ * "match_overlap" (1 = a batch of several chunks runs what follows a chunk's
+ * bound passes on a second stream of the context while the next chunk's bound
+ * passes start, default; 0 = everything on one stream; results are identical;
+ * either way the call's work is ordered before whatever follows it on the
+ * context).
  * Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */
 int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);

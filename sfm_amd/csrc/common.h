@@ -22,6 +22,12 @@ struct sfm_ctx {
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
     int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
+    int match_overlap = 1;           // 0: the matcher's chunks run one after the other on `stream` only
+    // Second stream of the batch matcher (what follows a chunk's bound passes), and the
+    // events that order the two: ev[0..1] a chunk's bound passes are done, ev[2..3] its lists are written
+    // (by chunk parity), ev[4] fork / join.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };
@@ -116,9 +122,9 @@ struct PinBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-// Event-pair timing of one kernel launch on ctx->stream.
-hipError_t sfm_span_begin(sfm_ctx *ctx, int which);
-hipError_t sfm_span_end(sfm_ctx *ctx, int which);
+// Event-pair timing of one kernel launch (on ctx->stream unless a stream is given).
+hipError_t sfm_span_begin(sfm_ctx *ctx, int which, hipStream_t st = nullptr);
+hipError_t sfm_span_end(sfm_ctx *ctx, int which, hipStream_t st = nullptr);
 void sfm_span_reset(sfm_ctx *ctx, int which);
 int sfm_num_sim_variants();
 

@@ -22,8 +22,11 @@ extern "C" int sfm_ctx_create(int device, sfm_ctx **ctx_out)
     if (!c) return SFM_ERR_OOM;
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < 5; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        sfm_ctx_destroy(c);
         return SFM_ERR_HIP;
     }
     *ctx_out = c;
@@ -35,10 +38,14 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     sfm_chain_scratch_free(ctx);
     sfm_pair_batch_free(ctx);
     sfm_pair_match_free(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (int k = 0; k < 5; k++)
+        if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     for (int w = 0; w < 2; w++)
         for (auto &s : ctx->span_pool[w]) {
             (void)hipEventDestroy(s.a);
@@ -73,6 +80,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->chain_table_entries = value;
     } else if (!strcmp(key, "hamming_mfma")) {
         ctx->hamming_mfma = value != 0;
+    } else if (!strcmp(key, "match_overlap")) {
+        ctx->match_overlap = value != 0;
     } else if (!strcmp(key, "ransac_split")) {
         ctx->ransac_split = value != 0;
     } else if (!strcmp(key, "ransac_filter")) {
@@ -89,7 +98,7 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
 
 void sfm_span_reset(sfm_ctx *ctx, int which) { ctx->span_used[which] = 0; }
 
-hipError_t sfm_span_begin(sfm_ctx *ctx, int which)
+hipError_t sfm_span_begin(sfm_ctx *ctx, int which, hipStream_t st)
 {
     if (ctx->span_used[which] == ctx->span_pool[which].size()) {
         sfm_ctx::Span s;
@@ -99,12 +108,12 @@ hipError_t sfm_span_begin(sfm_ctx *ctx, int which)
         if (r != hipSuccess) return r;
         ctx->span_pool[which].push_back(s);
     }
-    return hipEventRecord(ctx->span_pool[which][ctx->span_used[which]].a, ctx->stream);
+    return hipEventRecord(ctx->span_pool[which][ctx->span_used[which]].a, st ? st : ctx->stream);
 }
 
-hipError_t sfm_span_end(sfm_ctx *ctx, int which)
+hipError_t sfm_span_end(sfm_ctx *ctx, int which, hipStream_t st)
 {
-    return hipEventRecord(ctx->span_pool[which][ctx->span_used[which]++].b, ctx->stream);
+    return hipEventRecord(ctx->span_pool[which][ctx->span_used[which]++].b, st ? st : ctx->stream);
 }
 
 extern "C" int sfm_ctx_last_kernel_ms(sfm_ctx *ctx, int which, double *ms_out, int *launches_out)

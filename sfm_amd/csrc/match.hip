@@ -1301,15 +1301,31 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->work.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
     SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, res->pairs.reserve((size_t)(outTotalCap ? outTotalCap : 1) * sizeof(int2)));
-    SFM_HIP(ctx, res->cand.reserve((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)));
+    // Two chunks in flight: while chunk c + 1 runs its bound passes on the context's stream, the exact pass,
+    // the mutual check and the list output of chunk c run on a second stream, in the gaps the bound pass
+    // leaves (its blocks fill the register files, so most of that work runs while one bound pass drains
+    // and the next has not started: about a third of it is hidden).  The per-chunk buffers therefore exist twice (halves of one allocation
+    // each), taken by chunk parity.  Events: ev[0..1] a chunk's bound passes are done, ev[2..3] its lists
+    // are written and its buffers free again (by parity), ev[4] fork / join of the two streams.
+    const int nChunks = n_pairs > 0 ? (n_pairs + chunkPairs - 1) / chunkPairs : 0;
+    const bool overlap = ctx->match_overlap && nChunks > 1 && !want_m1m2;
+    const int sets = overlap ? 2 : 1;
+    const size_t candHalf = (size_t)round_up((int64_t)((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)), 256);
+    SFM_HIP(ctx, res->cand.reserve(candHalf * sets));
     const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
-    SFM_HIP(ctx, res->candCount.reserve((size_t)chunkPairs * maxQueues * sizeof(int)));
-    SFM_HIP(ctx, res->pairOvf.reserve((size_t)(chunkPairs + 4) * sizeof(int))); // flags, then how often each value was set
-    SFM_HIP(ctx, res->best.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(u64)));
-    SFM_HIP(ctx, res->ovfList.reserve((size_t)(chunkPairs + 1) * sizeof(int)));
-    SFM_HIP(ctx, res->counts.reserve((size_t)chunkPairs * sizeof(int)));
+    const size_t candCountHalf = (size_t)round_up((int64_t)((size_t)chunkPairs * maxQueues * sizeof(int)), 256);
+    SFM_HIP(ctx, res->candCount.reserve(candCountHalf * sets));
+    const size_t pairOvfHalf = (size_t)round_up((int64_t)((size_t)(chunkPairs + 4) * sizeof(int)), 256); // flags, then how often each value was set
+    SFM_HIP(ctx, res->pairOvf.reserve(pairOvfHalf * sets));
+    const size_t bestHalf = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(u64)), 256);
+    SFM_HIP(ctx, res->best.reserve(bestHalf * sets));
+    const size_t ovfListHalf = (size_t)round_up((int64_t)((size_t)(chunkPairs + 1) * sizeof(int)), 256);
+    SFM_HIP(ctx, res->ovfList.reserve(ovfListHalf * sets));
+    const size_t countsHalf = (size_t)round_up((int64_t)((size_t)chunkPairs * sizeof(int)), 256);
+    SFM_HIP(ctx, res->counts.reserve(countsHalf * sets));
     SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
-    if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve((size_t)(maxBest ? maxBest : 1) * sizeof(int)));
+    const size_t killHalf = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(int)), 256);
+    if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killHalf * sets));
     if (want_m1m2) {
         SFM_HIP(ctx, res->m1.reserve((size_t)(maxNA ? maxNA : 1) * sizeof(int32_t)));
         SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
@@ -1317,6 +1333,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     hipStream_t st = ctx->stream;
     SFM_HIP(ctx, hipMemsetAsync(res->offsets.p, 0, sizeof(int64_t), st));
     SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 4 * sizeof(u64), st));
+    if (overlap) { // the second stream starts where the first one stands
+        SFM_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[4], 0));
+    }
 
     MatchArgs g;
     g.desc16 = set->desc16.as<_Float16>();
@@ -1325,15 +1345,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.desc32 = set->desc32.as<float>();
     g.norms = set->norms.as<float>();
     g.pts = set->pts.as<double2>();
-    g.cand = res->cand.as<uint2>();
-    g.candCount = res->candCount.as<int>();
-    g.pairOvf = res->pairOvf.as<int>();
-    g.flagCount = res->pairOvf.as<int>() + chunkPairs;
     g.maxQueues = maxQueues;
     g.blockRows = BLOCK_ROWS;
     g.wavesPerBlock = wavesPerBlock;
-    g.best = res->best.as<u64>();
-    g.ovfList = res->ovfList.as<int>();
     g.stats = res->stats.as<u64>();
     g.candCap = candCap;
     g.dim = set->dim;
@@ -1341,13 +1355,27 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.threshold = threshold;
     g.maxDistSq = maxDistSq;
     g.ratioSq = (double)ratio * (double)ratio;
-    g.kill = ratio > 0.0f ? res->kill.as<int>() : nullptr;
 
     size_t ci = 0;
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
         const int np = c1 - c0;
         prepare_chunk(c0, c1, ci);
+        // this chunk's set of buffers; st = the stream of its bound passes
+        const int par = overlap ? (int)(ci & 1) : 0;
+        st = ctx->stream;
+        char *const bestBuf = res->best.as<char>() + par * bestHalf;
+        char *const candCountBuf = res->candCount.as<char>() + par * candCountHalf;
+        char *const pairOvfBuf = res->pairOvf.as<char>() + par * pairOvfHalf;
+        char *const killBuf = ratio > 0.0f ? res->kill.as<char>() + par * killHalf : nullptr;
+        int *const countsBuf = reinterpret_cast<int *>(res->counts.as<char>() + par * countsHalf);
+        g.cand = reinterpret_cast<uint2 *>(res->cand.as<char>() + par * candHalf);
+        g.candCount = reinterpret_cast<int *>(candCountBuf);
+        g.pairOvf = reinterpret_cast<int *>(pairOvfBuf);
+        g.flagCount = g.pairOvf + chunkPairs;
+        g.best = reinterpret_cast<u64 *>(bestBuf);
+        g.ovfList = reinterpret_cast<int *>(res->ovfList.as<char>() + par * ovfListHalf);
+        g.kill = reinterpret_cast<int *>(killBuf);
         SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.as<PairRec>() + c0, recs + c0, (size_t)np * sizeof(PairRec),
                                     hipMemcpyHostToDevice, st));
         {
@@ -1361,20 +1389,22 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         g.work = workList[0];
         g.orient = 0;
         int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
+        // the chunk two back is done with this set of buffers
+        if (overlap && ci >= 2) SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[2 + par], 0));
         if (bestLen > 0) {
-            SFM_HIP(ctx, hipMemsetAsync(res->best.p, 0, (size_t)bestLen * sizeof(u64), st));
+            SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)bestLen * sizeof(u64), st));
         }
-        SFM_HIP(ctx, hipMemsetAsync(res->candCount.p, 0, (size_t)np * maxQueues * sizeof(int), st));
-        SFM_HIP(ctx, hipMemsetAsync(res->pairOvf.p, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
+        SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)np * maxQueues * sizeof(int), st));
+        SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
         const int nblk = chunkWorkCount[0][ci];
         const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
         if (nblk > 0) {
             const bool cosine = metric == SFM_METRIC_COSINE;
             if (cosine) {
-                SFM_HIP(ctx, sfm_span_begin(ctx, 0));
+                SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
                 hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
-                SFM_HIP(ctx, sfm_span_end(ctx, 0));
+                SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
             }
             if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 g.onlyFlagged = 3;
@@ -1387,11 +1417,18 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             for (int o = 0; o < 2; o++) {
                 g.orient = o;
                 g.work = workList[o];
-                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0));
+                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.nWork = chunkWorkCount[o][ci];
                 hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(cosine ? std::min(g.nWork, walkGrid) : g.nWork),
                                    dim3(SIM_WAVES * 64), 0, st, g);
-                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0));
+                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
+            }
+            // The bound passes of consecutive chunks follow each other on this stream (each fills the device on
+            // its own, and their timing spans stay clean); the rest of the chunk moves to the second stream.
+            if (overlap) {
+                SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
+                st = ctx->stream2;
+                SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
             }
             g.onlyFlagged = 0;
             g.orient = 0;
@@ -1407,7 +1444,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             hipLaunchKernelGGL(match_overflow_list_kernel, dim3(1), dim3(256), 0, st, g, np);
             hipLaunchKernelGGL(match_exact_kernel, dim3(4 * ctx->n_cus), dim3(256), 0, st, g);
             if (ratio > 0.0f) { // second sweep: rows whose second best comes too close lose their best
-                SFM_HIP(ctx, hipMemsetAsync(res->kill.p, 0, (size_t)bestLen * sizeof(int), st));
+                SFM_HIP(ctx, hipMemsetAsync(killBuf, 0, (size_t)bestLen * sizeof(int), st));
                 if (candCap > 0) {
                     if (fast128)
                         hipLaunchKernelGGL((g.desc8u ? match_cand128_kernel<true, true> : match_cand128_kernel<false, true>),
@@ -1418,16 +1455,25 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 hipLaunchKernelGGL(ratio_rows_kernel, dim3(64, np), dim3(256), 0, st, g);
                 hipLaunchKernelGGL(ratio_apply_kernel, dim3(np), dim3(256), 0, st, g);
             }
+        } else if (overlap) { // a chunk without work: its memsets still precede what follows
+            SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
+            st = ctx->stream2;
+            SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
         }
-        hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
-                           res->counts.as<int>(), (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr,
-                           (int32_t *)nullptr);
-        hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, res->counts.as<int>(), np,
-                           res->offsets.as<int64_t>(), (int64_t)c0);
+        // (the scan continues the offsets of the chunk before: same stream, in order)
+        hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best, countsBuf,
+                           (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, countsBuf, np, res->offsets.as<int64_t>(),
+                           (int64_t)c0);
         hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
                            (int *)nullptr, res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(),
                            want_m1m2 ? res->m1.as<int32_t>() : nullptr, want_m1m2 ? res->m2.as<int32_t>() : nullptr);
+        if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[2 + par], st));
         SFM_HIP(ctx, hipGetLastError());
+    }
+    if (overlap) { // the caller's stream continues once both are done
+        SFM_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream2));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[4], 0));
     }
     return SFM_OK;
 }

@@ -175,6 +175,43 @@ def test_batch_ragged_exhaustive(ctx, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("metric,threshold,chunk", [(0, 0.95, 1), (0, 0.95, 3), (0, 0.3, 2),
+                                                    (1, 0.0, 2)])
+def test_chunks_on_two_streams_give_the_same_lists(ctx, oracle, metric, threshold, chunk):
+    """A batch of several chunks runs what follows a chunk's bound passes on a second stream while the next
+    chunk starts (two sets of per-chunk buffers).  Lists with and without that overlap, and across repeated
+    calls into one result object, are identical, and equal the CPU restatement's."""
+    counts = np.array([640, 257, 0, 900, 64, 511, 333], np.int32)
+    n = int(counts.max())
+    d, p, _ = synth.image_set(len(counts), n, seed=131)
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)])
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    pl = synth.exhaustive_pairs(len(counts)).astype(np.int32)
+    s = ctx.imageset(counts, desc, pts)
+    got = {}
+    ctx.set_option("pairs_per_launch", chunk)
+    try:
+        for ov in (1, 0):
+            ctx.set_option("match_overlap", ov)
+            res = None
+            for _ in range(3):  # reuse: the second and third call find both streams and both buffer sets used
+                res = s.match(pl, metric=metric, threshold=threshold, max_dist_sq=150.0 * 150.0, result=res)
+            got[ov] = (res.offsets().copy(), res.pairs().copy())
+            res.close()
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+        ctx.set_option("match_overlap", 1)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    off, pairs = got[1]
+    for k, (a, b) in enumerate(pl):
+        exp, _, _ = oracle.match(desc[starts[a]:starts[a + 1]], pts[starts[a]:starts[a + 1]],
+                                 desc[starts[b]:starts[b + 1]], pts[starts[b]:starts[b + 1]],
+                                 metric=metric, threshold=threshold, max_dist_sq=150.0 * 150.0)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp), f"pair {k} ({a},{b})"
+    s.close()
+
+
 def test_full_size_properties(ctx):
     """8192 x 8192 (the benchmark shape): size-independent properties instead of the oracle.
     Swapping the images transposes the match set; matching an image with itself is the identity
