@@ -755,20 +755,33 @@ template <bool U8, bool RATIO> __global__ __launch_bounds__(256) void match_cand
     const int nQueues = pair_queues(g, pr, p);
     const int cap = g.candCap / nQueues;
 
-    // exclusive prefix of the slice counts (nQueues <= 1024)
-    for (int q = tid; q < 1024; q += 256) prefix[q + 1] = (q < nQueues) ? g.candCount[p * g.maxQueues + q] : 0;
-    if (tid == 0) prefix[0] = 0;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int v[4];
+    // exclusive prefix of the slice counts (nQueues <= 1024): thread t owns slices 4t .. 4t + 3, the
+    // running sums go through one scan per wave and the four wave totals
+    __shared__ int waveSum[4];
+    {
+        int v[4], own = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int q = tid + 256 * u + 1;
-            v[u] = (q > d) ? prefix[q - d] : 0;
+            const int q = 4 * tid + u;
+            v[u] = (q < nQueues) ? g.candCount[p * g.maxQueues + q] : 0;
+            own += v[u];
         }
-        __syncthreads();
+        int incl = own;
 #pragma unroll
-        for (int u = 0; u < 4; u++) prefix[tid + 256 * u + 1] += v[u];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) waveSum[wave] = incl;
+        __syncthreads();
+        int run = incl - own;
+        for (int w = 0; w < wave; w++) run += waveSum[w];
+        if (tid == 0) prefix[0] = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            run += v[u];
+            prefix[4 * tid + u + 1] = run;
+        }
         __syncthreads();
     }
     const int total = prefix[nQueues];
