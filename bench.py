@@ -49,6 +49,8 @@ def main():
                     help="arithmetic of the matcher's similarity bound (the exact re-scoring is fp32 either way)")
     ap.add_argument("--first-slice", type=int, default=0,
                     help="rows of the first slice of adaptive RANSAC batches (0 = the library's default)")
+    ap.add_argument("--pairs-per-launch", type=int, default=0,
+                    help="image pairs per matcher chunk (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
@@ -77,6 +79,8 @@ def main():
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
     if args.first_slice > 0:
         ctx.set_option("hyps_per_launch", args.first_slice)
+    if args.pairs_per_launch > 0:
+        ctx.set_option("pairs_per_launch", args.pairs_per_launch)
 
     # ---- workload: weak scaling, pairs_per_gpu fixed ---------------------------------------
     pairs_per_gpu = args.images * (args.images - 1) // 2
