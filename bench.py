@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.95)
     ap.add_argument("--ratio", type=float, default=None,
                     help="also apply Lowe's second-best ratio test (extension; not the reference's matcher)")
-    ap.add_argument("--ransac-pairs", type=int, default=64)
+    ap.add_argument("--ransac-pairs", type=int, default=512, help="pairs per RANSAC batch (the stress shape has 10 000)")
     ap.add_argument("--ransac-corr", type=int, default=20000)
     ap.add_argument("--ransac-hyps", type=int, default=4096)
     ap.add_argument("--bound", choices=sorted(BOUNDS), default="int8",
