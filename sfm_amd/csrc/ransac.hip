@@ -162,26 +162,40 @@ __device__ __forceinline__ double sampson_loss(const double *K, const double E[3
 // and regions of consecutive pairs do not overlap (each takes 20 * ceil(n / 4) floats).
 __host__ __device__ inline size_t rec32_start(int64_t base, int p) { return (size_t)20 * (size_t)((base + 3 * (int64_t)p + 3) / 4); }
 
-__global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, int64_t total)
+// The values of a correspondence that the reference recomputes per hypothesis: both observations, x2h.x2h,
+// and obs = K * (ox, oy, 1) for both (solve.hpp:90-91).  With the pre-test on they are made where they are
+// needed (the rare exact evaluations) instead of being stored: 80 bytes per correspondence less to write.
+__device__ __forceinline__ void make_record(const RansacArgs &g, int64_t at, double r[9])
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= total) return;
-    const double2 a = g.x[k], b = g.y[k];
-    double *r = g.rec + k * REC_D;
+    const double2 a = g.x[at], b = g.y[at];
     r[0] = a.x;
     r[1] = a.y;
     r[2] = b.x;
     r[3] = b.y;
     r[4] = (b.x * b.x + b.y * b.y) + 1.0;
-    r[5] = (g.K[0] * a.x + g.K[3] * a.y) + g.K[6]; // solve.hpp:90-91, obs = K * (ox, oy, 1)
+    r[5] = (g.K[0] * a.x + g.K[3] * a.y) + g.K[6];
     r[6] = (g.K[1] * a.x + g.K[4] * a.y) + g.K[7];
     r[7] = (g.K[0] * b.x + g.K[3] * b.y) + g.K[6];
     r[8] = (g.K[1] * b.x + g.K[4] * b.y) + g.K[7];
+}
+
+__global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, int64_t total)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    double r[REC_D];
+    make_record(g, k, r);
+    if (!g.filter) { // the instances without the pre-test stage these records in LDS
+        double *dst = g.rec + k * REC_D;
+#pragma unroll
+        for (int i = 0; i < 9; i++) dst[i] = r[i];
+        dst[9] = 0.0;
+        return;
+    }
     // x1h.x1h for the scoring kernel's pre-test, or +inf for a correspondence it must not skip
     const double big = 1e6;
     const bool tame = fabs(r[5]) <= big && fabs(r[6]) <= big && fabs(r[7]) <= big && fabs(r[8]) <= big;
-    r[9] = tame ? (a.x * a.x + a.y * a.y) + 1.0 : INFINITY;
-    if (!g.filter) return;
+    r[9] = tame ? (r[0] * r[0] + r[1] * r[1]) + 1.0 : INFINITY;
     // fp32 record of the pre-test: x1, y1, fx x2 / c, fy y2 / c (the observation in pixels off the centre, in
     // units of the skip distance c = SKIP_FACTOR sqrt(maxSquaredError)) and the margin G that pays for the
     // rounding of the fp32 estimate (derived in the scoring kernel), or inf.  Correspondences 4j .. 4j + 3 of a
@@ -562,10 +576,12 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
             tot += e;
         }
     };
-    // (the pre-test instance queues indices relative to the pair, kChunk staying 0 for record(), and reads
-    // the fp64 record from global memory; the others index the chunk staged in LDS)
+    // (the pre-test instance queues indices relative to the pair, kChunk staying 0 for record(), and makes
+    // the fp64 record from the observations in global memory; the others index the chunk staged in LDS)
     auto evaluate = [&](int kk) {
-        const double *r = FILTER ? g.rec + (size_t)(base + kk) * REC_D : rec + kk * REC_D;
+        double made[9];
+        if (FILTER) make_record(g, base + kk, made);
+        const double *r = FILTER ? made : rec + kk * REC_D;
         record(kk, reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]));
     };
     auto drain = [&]() {
@@ -928,7 +944,9 @@ __global__ __launch_bounds__(256) void ransac_inlier_flag_kernel(const RansacArg
         double K[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) K[i] = g.K[i];
-        const double *r = g.rec + (base + k) * REC_D;
+        double made[9];
+        if (g.filter) make_record(g, base + k, made);
+        const double *r = g.filter ? made : g.rec + (base + k) * REC_D;
         double e;
         if (g.loss == SFM_LOSS_SAMPSON) {
             double E[3][3];
@@ -1283,6 +1301,16 @@ static int split_factor(const sfm_ctx *ctx, int n_pairs, int rows, int64_t total
     return (int)std::max<int64_t>(1, std::min<int64_t>((4 * ctx->n_cus + blocks - 1) / blocks, total / n_pairs / 16));
 }
 
+// The pre-test bounds the reprojection loss and needs K = [fx 0 cx; 0 fy cy; 0 0 1] with positive focal lengths
+// (K column-major: K(r,c) = K[r + 3c]).
+static bool pretest_applies(const sfm_ctx *ctx, const double *K, int loss)
+{
+    const double fx = K[0], fy = K[4];
+    return K[2] == 0.0 && K[5] == 0.0 && K[8] == 1.0 && K[1] == 0.0 && K[3] == 0.0 && fx > 0.0 && fy > 0.0 &&
+           std::isfinite(fx) && std::isfinite(fy) && std::isfinite(1.0 / fx) && std::isfinite(1.0 / fy) &&
+           ctx->ransac_filter != 0 && loss != SFM_LOSS_SAMPSON;
+}
+
 static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
                       const double *K, const int32_t *samples, int n_hyp, double maxSqErr, double successProb,
                       int adaptive, int loss, bool on_device, bool fit_only, sfm_ransac_batch **batch_inout,
@@ -1351,7 +1379,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         g.samples = b->samples.as<int32_t>();
     }
     SFM_HIP(ctx, b->corrOff.reserve((P1 + 1) * sizeof(int64_t)));
-    SFM_HIP(ctx, b->rec.reserve((size_t)(total ? total : 1) * REC_D * sizeof(double)));
+    // (with the pre-test on, the fp64 records are made where they are needed and not stored)
+    SFM_HIP(ctx, b->rec.reserve(pretest_applies(ctx, K, loss) ? 256 : (size_t)(total ? total : 1) * REC_D * sizeof(double)));
     SFM_HIP(ctx, b->rec32.reserve((rec32_start(total, n_pairs) + 40) * sizeof(float)));
     SFM_HIP(ctx, b->pose12.reserve(PH * 12 * sizeof(double)));
     SFM_HIP(ctx, b->counts.reserve(PH * sizeof(int)));
@@ -1387,9 +1416,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         // positive focal lengths: observations K*(x,y,1) are then pixels, and the epipolar line of a
         // hypothesis keeps a simple form in them (see the scoring kernel).
         const double fx = K[0], fy = K[4];
-        const bool ok = K[2] == 0.0 && K[5] == 0.0 && K[8] == 1.0 && K[1] == 0.0 && K[3] == 0.0 && fx > 0.0 && fy > 0.0 &&
-                        std::isfinite(fx) && std::isfinite(fy) && std::isfinite(1.0 / fx) && std::isfinite(1.0 / fy) &&
-                        ctx->ransac_filter != 0;
+        const bool ok = pretest_applies(ctx, K, loss);
         g.filter = ok ? 1 : 0;
         g.Ki[0] = ok ? 1.0 / fx : 0.0;
         g.Ki[1] = ok ? 1.0 / fy : 0.0;
@@ -1441,7 +1468,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             const int Z = split_factor(ctx, n_pairs, rows, total);
             SFM_HIP(ctx, sfm_span_begin(ctx, 1));
             const dim3 grid((rows + 255) / 256, n_pairs, Z);
-            const bool pretest = g.filter != 0 && loss != SFM_LOSS_SAMPSON;
+            const bool pretest = g.filter != 0;
             double *eb = nullptr;
             if (Z > 1) {
                 SFM_HIP(ctx, b->errBuf.reserve(errBytes));
