@@ -23,11 +23,11 @@ struct sfm_ctx {
     int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
     int match_overlap = 1;           // 0: the matcher's chunks run one after the other on `stream` only
-    // Second stream of the batch matcher (what follows a chunk's bound passes), and the
-    // events that order the two: ev[0..1] a chunk's bound passes are done, ev[2..3] its lists are written
-    // (by chunk parity), ev[4] fork / join.
+    // Second stream of the batch matcher (what follows a chunk's bound passes), and the events that order the
+    // two: ev[0..2] a chunk's bound passes are done, ev[3..5] its buffer set is clear again (by set), ev[6]
+    // fork / join.
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };

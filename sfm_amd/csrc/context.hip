@@ -24,7 +24,7 @@ extern "C" int sfm_ctx_create(int device, sfm_ctx **ctx_out)
     c->n_cus = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; ok && k < 5; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < 7; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         sfm_ctx_destroy(c);
         return SFM_ERR_HIP;
@@ -44,7 +44,7 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
     sfm_pair_match_free(ctx);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    for (int k = 0; k < 5; k++)
+    for (int k = 0; k < 7; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     for (int w = 0; w < 2; w++)
         for (auto &s : ctx->span_pool[w]) {

@@ -1314,31 +1314,33 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->work.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
     SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
     SFM_HIP(ctx, res->pairs.reserve((size_t)(outTotalCap ? outTotalCap : 1) * sizeof(int2)));
-    // Two chunks in flight: while chunk c + 1 runs its bound passes on the context's stream, the exact pass,
-    // the mutual check and the list output of chunk c run on a second stream, in the gaps the bound pass
-    // leaves (its blocks fill the register files, so most of that work runs while one bound pass drains
-    // and the next has not started: about a third of it is hidden).  The per-chunk buffers therefore exist twice (halves of one allocation
-    // each), taken by chunk parity.  Events: ev[0..1] a chunk's bound passes are done, ev[2..3] its lists
-    // are written and its buffers free again (by parity), ev[4] fork / join of the two streams.
+    // Chunks in flight: while chunk c + 1 runs its bound passes on the context's stream, the exact pass, the
+    // mutual check and the list output of chunk c run on a second stream, in the gaps the bound pass leaves
+    // (its blocks fill the register files: kernels with few registers run beside it, the exact pass mostly
+    // while one bound pass drains and the next has not started).  The per-chunk buffers exist up to three times
+    // (parts of one allocation each), taken in turn; the second stream clears a set for its next use as
+    // soon as the chunk's lists are written, so the first stream neither clears nor, as long as the second
+    // keeps up, waits.  Events: ev[0..2] a chunk's bound passes are done, ev[3..5] its set is clear again
+    // (by set), ev[6] fork / join of the two streams.
     const int nChunks = n_pairs > 0 ? (n_pairs + chunkPairs - 1) / chunkPairs : 0;
     const bool overlap = ctx->match_overlap && nChunks > 1 && !want_m1m2;
-    const int sets = overlap ? 2 : 1;
-    const size_t candHalf = (size_t)round_up((int64_t)((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)), 256);
-    SFM_HIP(ctx, res->cand.reserve(candHalf * sets));
+    const int sets = overlap ? std::min(3, nChunks) : 1;
+    const size_t candSet = (size_t)round_up((int64_t)((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)), 256);
+    SFM_HIP(ctx, res->cand.reserve(candSet * sets));
     const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
-    const size_t candCountHalf = (size_t)round_up((int64_t)((size_t)chunkPairs * maxQueues * sizeof(int)), 256);
-    SFM_HIP(ctx, res->candCount.reserve(candCountHalf * sets));
-    const size_t pairOvfHalf = (size_t)round_up((int64_t)((size_t)(chunkPairs + 4) * sizeof(int)), 256); // flags, then how often each value was set
-    SFM_HIP(ctx, res->pairOvf.reserve(pairOvfHalf * sets));
-    const size_t bestHalf = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(u64)), 256);
-    SFM_HIP(ctx, res->best.reserve(bestHalf * sets));
-    const size_t ovfListHalf = (size_t)round_up((int64_t)((size_t)(chunkPairs + 1) * sizeof(int)), 256);
-    SFM_HIP(ctx, res->ovfList.reserve(ovfListHalf * sets));
-    const size_t countsHalf = (size_t)round_up((int64_t)((size_t)chunkPairs * sizeof(int)), 256);
-    SFM_HIP(ctx, res->counts.reserve(countsHalf * sets));
+    const size_t candCountSet = (size_t)round_up((int64_t)((size_t)chunkPairs * maxQueues * sizeof(int)), 256);
+    SFM_HIP(ctx, res->candCount.reserve(candCountSet * sets));
+    const size_t pairOvfSet = (size_t)round_up((int64_t)((size_t)(chunkPairs + 4) * sizeof(int)), 256); // flags, then how often each value was set
+    SFM_HIP(ctx, res->pairOvf.reserve(pairOvfSet * sets));
+    const size_t bestSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(u64)), 256);
+    SFM_HIP(ctx, res->best.reserve(bestSet * sets));
+    const size_t ovfListSet = (size_t)round_up((int64_t)((size_t)(chunkPairs + 1) * sizeof(int)), 256);
+    SFM_HIP(ctx, res->ovfList.reserve(ovfListSet * sets));
+    const size_t countsSet = (size_t)round_up((int64_t)((size_t)chunkPairs * sizeof(int)), 256);
+    SFM_HIP(ctx, res->counts.reserve(countsSet * sets));
     SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
-    const size_t killHalf = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(int)), 256);
-    if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killHalf * sets));
+    const size_t killSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(int)), 256);
+    if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killSet * sets));
     if (want_m1m2) {
         SFM_HIP(ctx, res->m1.reserve((size_t)(maxNA ? maxNA : 1) * sizeof(int32_t)));
         SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
@@ -1347,8 +1349,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, hipMemsetAsync(res->offsets.p, 0, sizeof(int64_t), st));
     SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 4 * sizeof(u64), st));
     if (overlap) { // the second stream starts where the first one stands
-        SFM_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[4], 0));
+        SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
     }
 
     MatchArgs g;
@@ -1375,19 +1377,19 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         const int np = c1 - c0;
         prepare_chunk(c0, c1, ci);
         // this chunk's set of buffers; st = the stream of its bound passes
-        const int par = overlap ? (int)(ci & 1) : 0;
+        const int par = (int)(ci % (size_t)sets);
         st = ctx->stream;
-        char *const bestBuf = res->best.as<char>() + par * bestHalf;
-        char *const candCountBuf = res->candCount.as<char>() + par * candCountHalf;
-        char *const pairOvfBuf = res->pairOvf.as<char>() + par * pairOvfHalf;
-        char *const killBuf = ratio > 0.0f ? res->kill.as<char>() + par * killHalf : nullptr;
-        int *const countsBuf = reinterpret_cast<int *>(res->counts.as<char>() + par * countsHalf);
-        g.cand = reinterpret_cast<uint2 *>(res->cand.as<char>() + par * candHalf);
+        char *const bestBuf = res->best.as<char>() + par * bestSet;
+        char *const candCountBuf = res->candCount.as<char>() + par * candCountSet;
+        char *const pairOvfBuf = res->pairOvf.as<char>() + par * pairOvfSet;
+        char *const killBuf = ratio > 0.0f ? res->kill.as<char>() + par * killSet : nullptr;
+        int *const countsBuf = reinterpret_cast<int *>(res->counts.as<char>() + par * countsSet);
+        g.cand = reinterpret_cast<uint2 *>(res->cand.as<char>() + par * candSet);
         g.candCount = reinterpret_cast<int *>(candCountBuf);
         g.pairOvf = reinterpret_cast<int *>(pairOvfBuf);
         g.flagCount = g.pairOvf + chunkPairs;
         g.best = reinterpret_cast<u64 *>(bestBuf);
-        g.ovfList = reinterpret_cast<int *>(res->ovfList.as<char>() + par * ovfListHalf);
+        g.ovfList = reinterpret_cast<int *>(res->ovfList.as<char>() + par * ovfListSet);
         g.kill = reinterpret_cast<int *>(killBuf);
         SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.as<PairRec>() + c0, recs + c0, (size_t)np * sizeof(PairRec),
                                     hipMemcpyHostToDevice, st));
@@ -1402,13 +1404,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         g.work = workList[0];
         g.orient = 0;
         int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
-        // the chunk two back is done with this set of buffers
-        if (overlap && ci >= 2) SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[2 + par], 0));
-        if (bestLen > 0) {
-            SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)bestLen * sizeof(u64), st));
+        if (overlap && ci >= (size_t)sets) { // the chunk that had this set before has written its lists and cleared it
+            SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[3 + par], 0));
+        } else {
+            if (bestLen > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)bestLen * sizeof(u64), st));
+            SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)np * maxQueues * sizeof(int), st));
+            SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
         }
-        SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)np * maxQueues * sizeof(int), st));
-        SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
         const int nblk = chunkWorkCount[0][ci];
         const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
         if (nblk > 0) {
@@ -1481,12 +1483,17 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
                            (int *)nullptr, res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(),
                            want_m1m2 ? res->m1.as<int32_t>() : nullptr, want_m1m2 ? res->m2.as<int32_t>() : nullptr);
-        if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[2 + par], st));
+        if (overlap && ci + sets < (size_t)nChunks) { // clear the set for the chunk that takes it next (sizes: upper bounds)
+            if (maxBest > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)maxBest * sizeof(u64), st));
+            SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)chunkPairs * maxQueues * sizeof(int), st));
+            SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
+            SFM_HIP(ctx, hipEventRecord(ctx->ev[3 + par], st));
+        }
         SFM_HIP(ctx, hipGetLastError());
     }
     if (overlap) { // the caller's stream continues once both are done
-        SFM_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream2));
-        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[4], 0));
+        SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream2));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[6], 0));
     }
     return SFM_OK;
 }

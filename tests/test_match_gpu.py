@@ -175,11 +175,11 @@ def test_batch_ragged_exhaustive(ctx, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("metric,threshold,chunk", [(0, 0.95, 1), (0, 0.95, 3), (0, 0.3, 2),
+@pytest.mark.parametrize("metric,threshold,chunk", [(0, 0.95, 1), (0, 0.95, 3), (0, 0.95, 11), (0, 0.3, 2),
                                                     (1, 0.0, 2)])
 def test_chunks_on_two_streams_give_the_same_lists(ctx, oracle, metric, threshold, chunk):
     """A batch of several chunks runs what follows a chunk's bound passes on a second stream while the next
-    chunk starts (two sets of per-chunk buffers).  Lists with and without that overlap, and across repeated
+    chunk starts (up to three sets of per-chunk buffers: 21 pairs in chunks of 11 take two, the others three).  Lists with and without that overlap, and across repeated
     calls into one result object, are identical, and equal the CPU restatement's."""
     counts = np.array([640, 257, 0, 900, 64, 511, 333], np.int32)
     n = int(counts.max())
