@@ -523,7 +523,15 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
     static_assert(!FILTER || LOSS != SFM_LOSS_SAMPSON, "the pre-test bounds the reprojection error");
     constexpr int CH = FILTER ? SCORE_CH32 : SCORE_CH;
     __shared__ __attribute__((aligned(16))) double rec[FILTER ? 2 : SCORE_CH * REC_D];
-    __shared__ unsigned int pend[FILTER ? SCORE_QCAP : 1][256]; // per-lane queues of correspondence indices (relative to the pair)
+    // POOL (split launches with the pre-test): a cell is written to errBuf on its own, in no particular order,
+    // so the survivors of a wave go to one list that all 64 lanes drain together, 64 entries at a time,
+    // whichever rows they belong to.  Rows with many inliers (every cell a survivor) then no longer hold the
+    // rest of their wave up.
+    constexpr bool POOL = SPLIT && FILTER;
+    constexpr int POOL_CAP = 192; // fewer than 64 entries left by a drain + two correspondences x 64 rows
+    __shared__ unsigned int pend[(FILTER && !POOL) ? SCORE_QCAP : 1][256]; // per-lane queues of correspondence indices (relative to the pair)
+    __shared__ unsigned int poolK[POOL ? 4 : 1][POOL ? POOL_CAP : 1];   // correspondence (relative to the pair)
+    __shared__ unsigned char poolL[POOL ? 4 : 1][POOL ? POOL_CAP : 1];  // lane = row of the wave
     __shared__ __attribute__((aligned(16))) float rec32[FILTER ? (SCORE_CH32 / 4 + 2) * 20 : 4]; // + 2: the pipeline reads ahead
     const int p = blockIdx.y;
     const int tid = threadIdx.x;
@@ -588,6 +596,40 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < npend) != 0; i++)
             if (i < npend) evaluate(pend[i][tid]);
         npend = 0;
+    };
+    int poolCount = 0; // wave-uniform
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long activeMask = __builtin_amdgcn_ballot_w64(active);
+    auto pool_push = [&](int k, unsigned long long skipMask) __attribute__((always_inline)) {
+        const unsigned long long want = ~skipMask & activeMask;
+        if ((want >> lane) & 1ull) {
+            const int at = poolCount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+            poolK[POOL ? wave : 0][POOL ? at : 0] = (unsigned)k;
+            poolL[POOL ? wave : 0][POOL ? at : 0] = (unsigned char)lane;
+        } else if (active) {
+            errCol[(size_t)k * rows] = none;
+        }
+        poolCount += __builtin_popcountll(want);
+    };
+    auto pool_drain = [&](int take) { // the last `take` (<= 64) entries, one per lane
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < take) {
+            const int at = poolCount - take + lane;
+            const int k = (int)poolK[POOL ? wave : 0][POOL ? at : 0];
+            const int row = (int)blockIdx.x * 256 + wave * 64 + (int)poolL[POOL ? wave : 0][POOL ? at : 0]; // relative to hBegin
+            Pose Q;
+            load_pose(g.pose12 + ((size_t)p * g.H + g.hBegin + row) * 12, Q);
+            double r[9];
+            make_record(g, base + k, r);
+            const double e = reprojection_loss(K, Q, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            errBuf[((size_t)base + k) * rows + row] = (e < thr) ? e : none;
+        }
+        poolCount -= take;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     const float *rec32g = FILTER ? g.rec32 + rec32_start(base, p) : nullptr;
     // The instruction arbiter of a SIMD favours its oldest wave: of the four blocks a CU holds, which all start
@@ -661,6 +703,12 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
                 constexpr int OGE = 3; // ordered >=: false on NaN
                 const unsigned long long skipMask0 = __builtin_amdgcn_fcmpf(n2.x, q.x, OGE);
                 const unsigned long long skipMask1 = __builtin_amdgcn_fcmpf(n2.y, q.y, OGE);
+                if constexpr (POOL) {
+                    if (kk < m) pool_push(k0 + kk, skipMask0);
+                    if (kk + 1 < m) pool_push(k0 + kk + 1, skipMask1);
+                    while (poolCount >= 64) pool_drain(64);
+                    return;
+                }
                 if (!SPLIT && (skipMask0 & skipMask1) == __builtin_amdgcn_ballot_w64(true)) return;
                 const bool skip0 = (skipMask0 >> (tid & 63)) & 1ull, skip1 = (skipMask1 >> (tid & 63)) & 1ull;
                 if (kk < m) {
@@ -697,7 +745,11 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, d
         }
         __syncthreads();
     }
-    if (FILTER) drain(); // what the last pushes left
+    if (POOL) {
+        if (!waveIdle && poolCount > 0) pool_drain(poolCount);
+    } else if (FILTER) {
+        drain(); // what the last pushes left
+    }
     if (active && !SPLIT) {
         g.counts[(size_t)p * g.H + h] = count;
         g.toterr[(size_t)p * g.H + h] = tot;
