@@ -1495,8 +1495,11 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         // The first slice is as small as its launch can be made efficient: 256 rows (one block of rows
         // per pair; with most correspondences inliers the cap falls below that at once) when the scoring
         // launch can be split over correspondences with a moderate buffer, otherwise enough rows to fill
-        // the device.
-        int64_t h = 256 * std::max<int64_t>(1, (2560 + n_pairs - 1) / n_pairs);
+        // the device twice over (a CU holds four blocks of the scoring kernel: 8 blocks per CU are two full
+        // rounds, and with slices growing by four the later launches are whole rounds too when the pair count
+        // divides evenly).
+        const int64_t fill = 8 * (int64_t)ctx->n_cus;
+        int64_t h = 256 * std::max<int64_t>(1, (fill + n_pairs - 1) / n_pairs);
         if (split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
         if (ctx->hyps_per_launch > 0) h = 64 * ((ctx->hyps_per_launch + 63) / 64); // caller's first slice
         while (h < n_hyp) {
