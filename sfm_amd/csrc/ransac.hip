@@ -1109,8 +1109,6 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
 {
     __shared__ double red[4][45];
     __shared__ double M[9][9], V[9][9];
-    __shared__ double rot[2]; // c, s of the current rotation (s = 0: skip)
-    __shared__ int anyRot;
     __shared__ double cand[2][9], T12s[3];
     __shared__ int cnt4[4][4];
     __shared__ int chosen;
@@ -1160,13 +1158,21 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
     }
     __syncthreads();
 
-    // cyclic Jacobi: M <- J^T M J, V <- V J until no off-diagonal element matters
-    for (int sweep = 0; sweep < 40; sweep++) {
-        if (tid == 0) anyRot = 0;
-        __syncthreads();
-        for (int pp = 0; pp < 8; pp++) {
-            for (int qq = pp + 1; qq < 9; qq++) {
-                if (tid == 0) {
+    // cyclic Jacobi: M <- J^T M J, V <- V J until no off-diagonal element matters.  One wave does it (lanes
+    // 0..8 own one row / column element each per rotation; every lane works the rotation out for itself from
+    // the same three elements), so the 36 rotations of a sweep need no block barrier: the LDS operations of a
+    // wave are carried out in order.
+    if (wave == 0) {
+        auto wave_sync = [&]() __attribute__((always_inline)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        for (int sweep = 0; sweep < 40; sweep++) {
+            bool any = false;
+            for (int pp = 0; pp < 8; pp++) {
+                for (int qq = pp + 1; qq < 9; qq++) {
+                    wave_sync();
                     const double apq = M[pp][qq], app = M[pp][pp], aqq = M[qq][qq];
                     double c = 1.0, sn = 0.0;
                     if (apq != 0.0 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
@@ -1174,40 +1180,29 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
                         const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
                         c = 1.0 / sqrt(1.0 + t * t);
                         sn = t * c;
-                        anyRot = 1;
+                        any = true;
                     }
-                    rot[0] = c;
-                    rot[1] = sn;
-                }
-                __syncthreads();
-                const double c = rot[0], sn = rot[1];
-                if (sn != 0.0) {
-                    double mp = 0, mq = 0, vp = 0, vq = 0;
-                    if (tid < 9) { // columns pp, qq of M and V, element tid
-                        mp = M[tid][pp];
-                        mq = M[tid][qq];
-                        vp = V[tid][pp];
-                        vq = V[tid][qq];
-                        M[tid][pp] = c * mp - sn * mq;
-                        M[tid][qq] = sn * mp + c * mq;
-                        V[tid][pp] = c * vp - sn * vq;
-                        V[tid][qq] = sn * vp + c * vq;
-                    }
-                    __syncthreads();
-                    if (tid < 9) { // rows pp, qq of M, element tid
-                        mp = M[pp][tid];
-                        mq = M[qq][tid];
-                        M[pp][tid] = c * mp - sn * mq;
-                        M[qq][tid] = sn * mp + c * mq;
+                    if (sn != 0.0) { // the same in every lane
+                        if (lane < 9) { // columns pp, qq of M and V, element lane
+                            const double mp = M[lane][pp], mq = M[lane][qq], vp = V[lane][pp], vq = V[lane][qq];
+                            M[lane][pp] = c * mp - sn * mq;
+                            M[lane][qq] = sn * mp + c * mq;
+                            V[lane][pp] = c * vp - sn * vq;
+                            V[lane][qq] = sn * vp + c * vq;
+                        }
+                        wave_sync();
+                        if (lane < 9) { // rows pp, qq of M, element lane
+                            const double mp = M[pp][lane], mq = M[qq][lane];
+                            M[pp][lane] = c * mp - sn * mq;
+                            M[qq][lane] = sn * mp + c * mq;
+                        }
                     }
                 }
-                __syncthreads();
             }
+            if (!any) break;
         }
-        const int again = anyRot; // written before the last barrier of the sweep
-        __syncthreads();          // everyone has read it before thread 0 clears it again
-        if (!again) break;
     }
+    __syncthreads();
 
     // 2. candidates
     if (tid == 0) {
