@@ -60,6 +60,9 @@ def lib() -> C.CDLL:
     L.sfm_oracle_svd3.argtypes = [_f64p, _f64p, _f64p, _f64p]
     L.sfm_oracle_null_vector.argtypes = [_f64p, C.c_int, _f64p]
     L.sfm_oracle_triangulate.argtypes = [_f64p, _f64p, _f64p, _f64p]
+    L.sfm_oracle_triangulate_normal_equations.argtypes = [_f64p, _f64p, _f64p, _f64p]
+    L.sfm_oracle_score_cells.argtypes = [_f64p, _f64p, C.c_int, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p]
+    L.sfm_oracle_score_cells.restype = None
     L.sfm_oracle_adaptive_max_iter.restype = C.c_int
     L.sfm_oracle_adaptive_max_iter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
     L.sfm_oracle_ransac.restype = C.c_int
@@ -175,6 +178,28 @@ def triangulate(a, b, T):
     lib().sfm_oracle_triangulate(np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64),
                                  np.ascontiguousarray(T, np.float64), out)
     return out
+
+
+def triangulate_normal_equations(a, b, T):
+    """The 3x2 least squares through the normal equations (not the reference's route; measurement only)."""
+    out = np.zeros(2)
+    lib().sfm_oracle_triangulate_normal_equations(np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64),
+                                                  np.ascontiguousarray(T, np.float64), out)
+    return out
+
+
+def score_cells(x, y, K, pose12, method=0):
+    """Depth before the float cast and default loss of every (hypothesis, correspondence) cell.
+    method 0: the QR solve (what the restatement uses), 1: normal equations."""
+    x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
+    y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
+    pose12 = np.ascontiguousarray(pose12, np.float64).reshape(-1, 12)
+    K = np.asfortranarray(K, np.float64).reshape(-1, order="F").copy()
+    H, n = len(pose12), len(x)
+    lam = np.zeros((H, n))
+    err = np.zeros((H, n))
+    lib().sfm_oracle_score_cells(x, y, n, K, pose12, H, int(method), lam.reshape(-1), err.reshape(-1))
+    return lam, err
 
 
 def adaptive_max_iter(n_inliers, n_total, min_n, success_prob) -> int:

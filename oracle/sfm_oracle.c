@@ -12,11 +12,16 @@
  *   - the matcher uses no third-party arithmetic: every fp32 operation below
  *     is the one the reference source spells out, in the same order
  *     (build with -ffp-contract=off, no -ffast-math);
- *   - the linear algebra that the reference delegates to Eigen >= 3.3
- *     (JacobiSVD of the 8x9 system and of the 3x3 essential matrix,
- *     colPivHouseholderQr().solve of the 3x2 triangulation system) is
- *     replaced by the stated algorithms below; tests cross-check them against
- *     LAPACK (numpy.linalg.svd / lstsq) to 1e-9.
+ *   - the linear algebra that the reference delegates to Eigen >= 3.3 (a
+ *     dependency absent from the reference tree and from this environment;
+ *     CMakeLists.txt:27 pins no version): JacobiSVD of the 8x9 system and of
+ *     the 3x3 essential matrix are replaced by the stated algorithms below
+ *     (their results are unique up to the sign conventions the model cancels);
+ *     colPivHouseholderQr().solve of the 3x2 triangulation system is restated
+ *     from Eigen's published algorithm, operation by operation.  Tests
+ *     cross-check all three against LAPACK (numpy.linalg.svd, SVD-based least
+ *     squares) and count, over many seeds, the (hypothesis, correspondence)
+ *     inlier decisions on which the restatement and LAPACK disagree.
  *
  * Reference files followed (paths relative to the reference tree):
  *   submodules/match/match.hpp:18-46     dotProduct, cosineSimilarity
@@ -408,13 +413,135 @@ static void svd3(const double e[3][3], double U[3][3], double S[3], double V[3][
 }
 
 /*
- * Least-squares solution of [-a, b] * lambda = T (3x2 system), standing in
- * for A_tri.colPivHouseholderQr().solve(T) (eightPoint.cpp:321,363) through
- * the normal equations solved by Cramer's rule.  bb = b.b is passed in
- * because callers hoist it per correspondence.
+ * Least-squares solution of [-a, b] * lambda = T (3x2 system) the way the reference gets it:
+ * A_tri.colPivHouseholderQr().solve(T) (eightPoint.cpp:321,363; twins :162,:214).  Eigen is a
+ * third-party dependency that is absent here (CMakeLists.txt:27 asks for any version >= 3.3), so
+ * this restates its published algorithm -- ColPivHouseholderQR::computeInPlace and _solve_impl,
+ * MatrixBase::makeHouseholder and applyHouseholderOnTheLeft of Eigen 3.3/3.4 -- operation by
+ * operation for a 3x2 matrix:
+ *   - column norms sqrt((c0^2 + c1^2) + c2^2); the larger column becomes the first pivot, the
+ *     first of equals (maxCoeff);
+ *   - reflector of a column (c0, tail): beta = -sign(c0) sqrt(c0^2 + |tail|^2) (sign(0) = +),
+ *     essential = tail / (c0 - beta), tau = (beta - c0) / beta; a tail with |tail|^2 <= DBL_MIN
+ *     gives tau = 0, beta = c0;
+ *   - applying it to a vector (w0, w): tmp = essential.w + w0; w0 -= tau tmp;
+ *     w -= tmp (tau essential); skipped when tau = 0;
+ *   - the second column's norm is downdated as in LAPACK's xGEQPF (it only feeds the rank
+ *     decision: a second pivot whose squared norm is below (eps max norm)^2 * 2/3 is dropped and
+ *     its unknown set to 0);
+ *   - c = Q^T T by the two reflectors in turn, back substitution (c1 /= R11; c0 -= c1 R01;
+ *     c0 /= R00, each division skipped for a zero numerator), then the column permutation.
+ * PARITY UNPINNED at the level of single roundings: no output of Eigen itself pins this order of
+ * operations; tests compare it with LAPACK (SVD-based least squares) to a few ulps times the
+ * condition number.  bb = b.b is passed in because callers hoist it per correspondence.
  */
+static inline void householder2(double c0, double t1, double t2, int tail_len, double *beta, double *tau,
+                                double *e1, double *e2)
+{
+    /* MatrixBase::makeHouseholder on (c0, t1[, t2]) */
+    const double tailSqNorm = (tail_len == 2) ? t1 * t1 + t2 * t2 : t1 * t1;
+    if (tailSqNorm <= 2.2250738585072014e-308) { /* (std::numeric_limits<double>::min)() */
+        *tau = 0.0;
+        *beta = c0;
+        *e1 = 0.0;
+        *e2 = 0.0;
+    } else {
+        double b = sqrt(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0)
+            b = -b;
+        *e1 = t1 / (c0 - b);
+        *e2 = (tail_len == 2) ? t2 / (c0 - b) : 0.0;
+        *tau = (b - c0) / b;
+        *beta = b;
+    }
+}
+
 static inline void triangulate_lambdas(const double a[3], const double b[3], double bb,
                                        const double T[3], double *lambda0, double *lambda1)
+{
+    const double eps = 2.220446049250313e-16;
+    double p[3] = {-a[0], -a[1], -a[2]}; /* A_tri.col(0) = -Rx1 */
+    double q[3] = {b[0], b[1], b[2]};    /* A_tri.col(1) = x2 */
+    double n0 = sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    double n1 = sqrt(bb);
+    const double maxn = (n1 > n0) ? n1 : n0;
+    const double threshold_helper = ((maxn * eps) * (maxn * eps)) / 3.0;
+    int nonzero_pivots = 2;
+    const int swapped = (n1 > n0); /* first pivot: the column of the largest norm, first of equals */
+    /* (the first pivot's squared norm is never below (eps max norm)^2: both pivots count so far) */
+    if (swapped) {
+        for (int i = 0; i < 3; i++) {
+            double t = p[i];
+            p[i] = q[i];
+            q[i] = t;
+        }
+        n1 = n0;
+    }
+    /* k = 0 */
+    double beta0, tau0, e01, e02;
+    householder2(p[0], p[1], p[2], 2, &beta0, &tau0, &e01, &e02);
+    if (tau0 != 0.0) {
+        double tmp = e01 * q[1] + e02 * q[2];
+        tmp = tmp + q[0];
+        q[0] = q[0] - tau0 * tmp;
+        q[1] = q[1] - tmp * (tau0 * e01);
+        q[2] = q[2] - tmp * (tau0 * e02);
+    }
+    /* norm of the remaining column, downdated (it was computed directly a moment ago, so the
+     * ratio updated / direct is 1) */
+    double upd = n1;
+    if (upd != 0.0) {
+        double temp = fabs(q[0]) / upd;
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        const double temp2 = temp * ((upd / n1) * (upd / n1));
+        if (temp2 <= 1.4901161193847656e-08) /* sqrt(eps) */
+            upd = sqrt(q[1] * q[1] + q[2] * q[2]);
+        else
+            upd = upd * sqrt(temp);
+    }
+    /* k = 1 */
+    if (nonzero_pivots == 2 && upd * upd < threshold_helper * 2.0)
+        nonzero_pivots = 1;
+    double beta1, tau1, e11, unused;
+    householder2(q[1], q[2], 0.0, 1, &beta1, &tau1, &e11, &unused);
+
+    /* _solve_impl */
+    double c[3] = {T[0], T[1], T[2]};
+    double s0 = 0.0, s1 = 0.0;
+    if (nonzero_pivots > 0) {
+        if (tau0 != 0.0) {
+            double tmp = e01 * c[1] + e02 * c[2];
+            tmp = tmp + c[0];
+            c[0] = c[0] - tau0 * tmp;
+            c[1] = c[1] - tmp * (tau0 * e01);
+            c[2] = c[2] - tmp * (tau0 * e02);
+        }
+        if (nonzero_pivots == 2) {
+            if (tau1 != 0.0) {
+                double tmp = e11 * c[2];
+                tmp = tmp + c[1];
+                c[1] = c[1] - tau1 * tmp;
+            }
+            if (c[1] != 0.0) {
+                c[1] = c[1] / beta1;
+                c[0] = c[0] - c[1] * q[0];
+            }
+            s1 = c[1];
+        }
+        if (c[0] != 0.0)
+            c[0] = c[0] / beta0;
+        s0 = c[0];
+    }
+    *lambda0 = swapped ? s1 : s0;
+    *lambda1 = swapped ? s0 : s1;
+}
+
+/* The same least squares through the normal equations and Cramer's rule.  Not what the reference
+ * does (it squares the condition number); kept only so that the tests can measure how often it
+ * would have decided differently from the QR solve above. */
+static inline void triangulate_lambdas_normal_equations(const double a[3], const double b[3], double bb,
+                                                        const double T[3], double *lambda0, double *lambda1)
 {
     double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
     double ab = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
@@ -705,6 +832,45 @@ void sfm_oracle_triangulate(const double *a, const double *b, const double *T, d
 {
     double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
     triangulate_lambdas(a, b, bb, T, &lambdas2[0], &lambdas2[1]);
+}
+
+void sfm_oracle_triangulate_normal_equations(const double *a, const double *b, const double *T, double *lambdas2)
+{
+    double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    triangulate_lambdas_normal_equations(a, b, bb, T, &lambdas2[0], &lambdas2[1]);
+}
+
+/* Every (hypothesis, correspondence) cell of RANSAC.cpp:213-221 on its own, for the tests that count
+ * decisions: lambda_out[h][k] = the camera-1 depth before the float cast, err_out[h][k] = the default
+ * loss.  pose12[h] = R row-major then T.  method 0 = the QR solve, 1 = the normal equations. */
+void sfm_oracle_score_cells(const double *x, const double *y, int n, const double *K, const double *pose12, int H,
+                            int method, double *lambda_out, double *err_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < H; h++) {
+        double R[3][3], T[3];
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++)
+                R[i][j] = pose12[(size_t)h * 12 + 3 * i + j];
+            T[i] = pose12[(size_t)h * 12 + 9 + i];
+        }
+        for (int k = 0; k < n; k++) {
+            const double x1 = x[2 * k], y1 = x[2 * k + 1], x2 = y[2 * k], y2 = y[2 * k + 1];
+            double a[3];
+            rot_apply_h(R, x1, y1, a);
+            const double b[3] = {x2, y2, 1.0};
+            const double bb = (x2 * x2 + y2 * y2) + 1.0;
+            double l0, l1;
+            if (method == 1)
+                triangulate_lambdas_normal_equations(a, b, bb, T, &l0, &l1);
+            else
+                triangulate_lambdas(a, b, bb, T, &l0, &l1);
+            const double l = (double)(float)l0;
+            const double pt[3] = {l * x1, l * y1, l};
+            lambda_out[(size_t)h * n + k] = l0;
+            err_out[(size_t)h * n + k] = default_loss(K, x1, y1, x2, y2, pt, R, T);
+        }
+    }
 }
 
 /* RANSAC.cpp:14-32 */

@@ -5,7 +5,7 @@
 // options.loss (solve/solve.hpp:85-95,119-124), for an explicit table of 8-index sample rows
 // taken in row order:
 //   ransac_prep_kernel   per correspondence: values the reference recomputes per hypothesis
-//                        (K*obs of solve.hpp:91, x2.x2 of the 3x2 normal equations)
+//                        (K*obs of solve.hpp:91, x2h.x2h of the 3x2 system's second column)
 //   ransac_fit_kernel    one hypothesis per lane: 8x9 null vector, 3x3 SVD, the four (R,T)
 //                        candidates and the cheirality vote (eightPoint.cpp:243-344)
 //   ransac_score_kernel  one hypothesis per lane, correspondences staged in LDS and read as
@@ -17,8 +17,8 @@
 // All fp64 arithmetic below is written operation by operation (this file is compiled with
 // contraction off): same products, same sums, same order as the CPU restatement the tests
 // compare against, so counts and error sums agree bit for bit.  Eigen's JacobiSVD and
-// colPivHouseholderQr are replaced by: Householder QR of A^T for the null vector, one-sided
-// Jacobi for the 3x3 SVD, normal equations for the 3x2 least squares.
+// JacobiSVD is replaced by Householder QR of A^T for the null vector and one-sided Jacobi for the 3x3
+// SVD; colPivHouseholderQr().solve of the 3x2 triangulation system is followed operation by operation.
 #include "common.h"
 
 #include <cmath>
@@ -81,18 +81,117 @@ __device__ __forceinline__ void rot_apply_h(const double R[3][3], double x, doub
     for (int i = 0; i < 3; i++) out[i] = (R[i][0] * x + R[i][1] * y) + R[i][2];
 }
 
-// Least squares of [-a, b] * lambda = T with b = (x2, y2, 1), bb = b.b, through the normal
-// equations (stands in for colPivHouseholderQr().solve, eightPoint.cpp:321,363).
+// Least squares of [-a, b] * lambda = T with b = (x2, y2, 1), bb = b.b, the way the reference solves it:
+// A_tri.colPivHouseholderQr().solve(T) (eightPoint.cpp:321,363).  Eigen's algorithm (ColPivHouseholderQR::
+// computeInPlace / _solve_impl, makeHouseholder, applyHouseholderOnTheLeft) written out for a 3x2 matrix, in
+// the operation order of the CPU restatement the tests compare with:
+//   factor: the column of the larger norm (the first of equals) is the first pivot; a reflector of
+//           (c0, tail) is beta = -sign(c0) sqrt(c0^2 + |tail|^2), essential = tail / (c0 - beta),
+//           tau = (beta - c0) / beta, or tau = 0, beta = c0 for a vanishing tail; the second column's norm is
+//           downdated (LAPACK xGEQPF) and only decides whether the second pivot counts;
+//   solve:  c = Q^T T by the reflectors in turn, back substitution, column permutation.
+// The factorisation does not depend on T, and every operation of the solve commutes with negation, so the
+// solution for -T is the negated solution for T, bit for bit: the cheirality vote factors once per rotation.
+struct Qr32 {
+    double beta0, tau0, e01, e02, r01, beta1, tau1, e11;
+    int pivots;   // nonzero pivots: 2, or 1 when the second column vanishes against the first
+    bool swapped; // b was the first pivot
+};
+
+__device__ __forceinline__ void householder_make(double c0, double t1, double t2, bool two, double &beta, double &tau,
+                                                 double &e1, double &e2)
+{
+    const double tailSqNorm = two ? t1 * t1 + t2 * t2 : t1 * t1;
+    if (tailSqNorm <= 2.2250738585072014e-308) {
+        tau = 0.0;
+        beta = c0;
+        e1 = 0.0;
+        e2 = 0.0;
+    } else {
+        double b = sqrt(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0) b = -b;
+        e1 = t1 / (c0 - b);
+        e2 = two ? t2 / (c0 - b) : 0.0;
+        tau = (b - c0) / b;
+        beta = b;
+    }
+}
+
+__device__ __forceinline__ Qr32 qr32_factor(const double a[3], double x2, double y2, double bb)
+{
+    const double eps = 2.220446049250313e-16;
+    Qr32 F;
+    double p0 = -a[0], p1 = -a[1], p2 = -a[2];
+    double q0 = x2, q1 = y2, q2 = 1.0;
+    const double n0 = sqrt((p0 * p0 + p1 * p1) + p2 * p2);
+    double n1 = sqrt(bb);
+    const double maxn = (n1 > n0) ? n1 : n0;
+    const double threshold_helper = ((maxn * eps) * (maxn * eps)) / 3.0;
+    F.pivots = 2;
+    F.swapped = n1 > n0;
+    if (F.swapped) {
+        double t = p0; p0 = q0; q0 = t;
+        t = p1; p1 = q1; q1 = t;
+        t = p2; p2 = q2; q2 = t;
+        n1 = n0;
+    }
+    householder_make(p0, p1, p2, true, F.beta0, F.tau0, F.e01, F.e02);
+    if (F.tau0 != 0.0) {
+        double tmp = F.e01 * q1 + F.e02 * q2;
+        tmp = tmp + q0;
+        q0 = q0 - F.tau0 * tmp;
+        q1 = q1 - tmp * (F.tau0 * F.e01);
+        q2 = q2 - tmp * (F.tau0 * F.e02);
+    }
+    double upd = n1;
+    if (upd != 0.0) {
+        double temp = fabs(q0) / upd;
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        const double temp2 = temp * ((upd / n1) * (upd / n1));
+        if (temp2 <= 1.4901161193847656e-08) upd = sqrt(q1 * q1 + q2 * q2);
+        else upd = upd * sqrt(temp);
+    }
+    if (upd * upd < threshold_helper * 2.0) F.pivots = 1;
+    double unused;
+    householder_make(q1, q2, 0.0, false, F.beta1, F.tau1, F.e11, unused);
+    F.r01 = q0;
+    return F;
+}
+
+__device__ __forceinline__ void qr32_solve(const Qr32 &F, const double T[3], double &l0, double &l1)
+{
+    double c0 = T[0], c1 = T[1], c2 = T[2];
+    double s1 = 0.0;
+    if (F.tau0 != 0.0) {
+        double tmp = F.e01 * c1 + F.e02 * c2;
+        tmp = tmp + c0;
+        c0 = c0 - F.tau0 * tmp;
+        c1 = c1 - tmp * (F.tau0 * F.e01);
+        c2 = c2 - tmp * (F.tau0 * F.e02);
+    }
+    if (F.pivots == 2) {
+        if (F.tau1 != 0.0) {
+            double tmp = F.e11 * c2;
+            tmp = tmp + c1;
+            c1 = c1 - F.tau1 * tmp;
+        }
+        if (c1 != 0.0) {
+            c1 = c1 / F.beta1;
+            c0 = c0 - c1 * F.r01;
+        }
+        s1 = c1;
+    }
+    if (c0 != 0.0) c0 = c0 / F.beta0;
+    l0 = F.swapped ? s1 : c0;
+    l1 = F.swapped ? c0 : s1;
+}
+
 __device__ __forceinline__ void triangulate_lambdas(const double a[3], double x2, double y2, double bb,
                                                     const double T[3], double &l0, double &l1)
 {
-    const double aa = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
-    const double ab = (a[0] * x2 + a[1] * y2) + a[2];
-    const double aT = (a[0] * T[0] + a[1] * T[1]) + a[2] * T[2];
-    const double bT = (x2 * T[0] + y2 * T[1]) + T[2];
-    const double det = aa * bb - ab * ab;
-    l0 = (ab * bT - bb * aT) / det;
-    l1 = (aa * bT - ab * aT) / det;
+    const Qr32 F = qr32_factor(a, x2, y2, bb);
+    qr32_solve(F, T, l0, l1);
 }
 
 // Default loss (solve.hpp:119-124) of one prepared correspondence under pose (R, T).
@@ -445,20 +544,21 @@ __global__ __launch_bounds__(64) void ransac_fit_kernel(const RansacArgs g)
     }
     const double T12[3] = {U[0][2], U[1][2], U[2][2]};
 
-    // eightPoint.cpp:296-337: cheirality vote over the 8 sample points, first strict maximum
+    // eightPoint.cpp:296-337: cheirality vote over the 8 sample points, first strict maximum.  Candidates
+    // 2r and 2r + 1 share the rotation and have opposite translations: one factorisation, one solve, and
+    // the solution for -T is the negated one.
     int cnt[4] = {0, 0, 0, 0};
     for (int i = 0; i < 8; i++) {
         const double2 a = g.x[base + idx[i]], b = g.y[base + idx[i]];
         const double bb = (b.x * b.x + b.y * b.y) + 1.0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const double sgn = (c & 1) ? -1.0 : 1.0;
-            const double Tc[3] = {sgn * T12[0], sgn * T12[1], sgn * T12[2]};
+        for (int r = 0; r < 2; r++) {
             double av[3];
-            rot_apply_h((c < 2) ? R1 : R2, a.x, a.y, av);
+            rot_apply_h(r ? R2 : R1, a.x, a.y, av);
             double l0, l1;
-            triangulate_lambdas(av, b.x, b.y, bb, Tc, l0, l1);
-            if (l0 > 0 && l1 > 0) cnt[c]++;
+            triangulate_lambdas(av, b.x, b.y, bb, T12, l0, l1);
+            if (l0 > 0 && l1 > 0) cnt[2 * r]++;
+            if (-l0 > 0 && -l1 > 0) cnt[2 * r + 1]++;
         }
     }
     int maxIndex = 0, maxPoints = 0;
@@ -515,7 +615,7 @@ __device__ unsigned long long g_scoreTimes[3 * 8192];
 extern "C" int sfm_debug_score_times(unsigned long long *out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scoreTimes), n * 8); }
 #endif
 template <int LOSS, bool SPLIT, bool FILTER>
-__global__ __launch_bounds__(256) void ransac_score_kernel(const RansacArgs g, double *__restrict__ errBuf)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !SPLIT ? 4 : 1))) void ransac_score_kernel(const RansacArgs g, double *__restrict__ errBuf)
 {
 #ifdef SFM_DEBUG_TIMES
     const unsigned long long dbgT0 = wall_clock64();
@@ -1249,14 +1349,13 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
         const double2 a = g.x[at], b = g.y[at];
         const double bb = (b.x * b.x + b.y * b.y) + 1.0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const double sgn = (c & 1) ? -1.0 : 1.0;
-            const double Tc[3] = {sgn * T12[0], sgn * T12[1], sgn * T12[2]};
+        for (int r = 0; r < 2; r++) { // candidates 2r, 2r + 1: same rotation, opposite translations
             double av[3];
-            rot_apply_h(Rc[c >> 1], a.x, a.y, av);
+            rot_apply_h(Rc[r], a.x, a.y, av);
             double l0, l1;
-            triangulate_lambdas(av, b.x, b.y, bb, Tc, l0, l1);
-            if (l0 > 0 && l1 > 0) cnt[c]++;
+            triangulate_lambdas(av, b.x, b.y, bb, T12, l0, l1);
+            if (l0 > 0 && l1 > 0) cnt[2 * r]++;
+            if (-l0 > 0 && -l1 > 0) cnt[2 * r + 1]++;
         }
     }
 #pragma unroll

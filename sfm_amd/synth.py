@@ -86,9 +86,9 @@ def _rodrigues(axis, angle):
 
 
 def two_view(n_corr: int, inlier_ratio: float = 0.15, seed: int = 7, noise_px: float = 0.5, K=None,
-             max_rot_deg: float = 20.0):
+             max_rot_deg: float = 20.0, depth=(2.0, 10.0)):
     """Correspondences of one image pair: inliers from a random relative pose (rotation up to
-    max_rot_deg, unit baseline, depths 2..10 baselines, Gaussian pixel noise), outliers uniform in
+    max_rot_deg, unit baseline, depths `depth` in baselines, Gaussian pixel noise), outliers uniform in
     both images.  Returns dict(x, y [n,2] K^-1-normalised, R, T, inlier_mask, K)."""
     K = default_K() if K is None else np.asarray(K, np.float64)
     Kinv = np.linalg.inv(K)
@@ -104,8 +104,8 @@ def two_view(n_corr: int, inlier_ratio: float = 0.15, seed: int = 7, noise_px: f
     while got < n_in:
         m = (n_in - got) * 2 + 16
         u = np.stack([rng.uniform(0, IMAGE_W, m), rng.uniform(0, IMAGE_H, m), np.ones(m)], axis=1)
-        depth = rng.uniform(2.0, 10.0, m)
-        X = (u @ Kinv.T) * depth[:, None]
+        z = rng.uniform(depth[0], depth[1], m)
+        X = (u @ Kinv.T) * z[:, None]
         X2 = X @ R.T + T
         ok = X2[:, 2] > 0.1
         p2 = (X2 / X2[:, 2:3]) @ K.T

@@ -212,6 +212,34 @@ def test_chunks_on_two_streams_give_the_same_lists(ctx, oracle, metric, threshol
     s.close()
 
 
+@pytest.mark.parametrize("sim_variant", [1, 0])
+@pytest.mark.parametrize("gate", [1e8, 1e4])
+def test_benchmark_pair_against_restatement(ctx, oracle, sim_variant, gate):
+    """The benchmark's own configuration at full size: images 0 and 1 of its generator (seed 2026, 8192
+    features each), threshold 0.95, with both similarity bounds and both pixel gates.  Pair list, matches1
+    and matches2 equal those of matchTwoSided (match.cpp:24-94), through the batch entry point and the
+    single-pair one."""
+    d, p, c = synth.image_set(2, 8192, seed=2026)
+    exp, e1, e2 = oracle.match(d[:8192], p[:8192], d[8192:], p[8192:], threshold=0.95, max_dist_sq=gate)
+    assert len(exp) > 2000
+    ctx.set_option("sim_variant", sim_variant)
+    try:
+        got, g1, g2 = ctx.match_pair(d[:8192], p[:8192], d[8192:], p[8192:], threshold=0.95, max_dist_sq=gate,
+                                     return_best=True)
+        assert np.array_equal(g1, e1) and np.array_equal(g2, e2) and np.array_equal(got, exp)
+        s = ctx.imageset(c, d, p)
+        res = s.match(np.array([[0, 1], [1, 0]], np.int32), threshold=0.95, max_dist_sq=gate)
+        off, pairs = res.offsets(), res.pairs()
+        assert np.array_equal(pairs[off[0]:off[1]], exp)
+        rev, _, _ = oracle.match(d[8192:], p[8192:], d[:8192], p[:8192], threshold=0.95, max_dist_sq=gate)
+        assert np.array_equal(pairs[off[1]:off[2]], rev)
+        assert res.stats()[1] == 0  # nothing fell back to cell-by-cell scoring
+        res.close()
+        s.close()
+    finally:
+        ctx.set_option("sim_variant", int(__import__("os").environ.get("SFM_SIM_VARIANT", "1")))
+
+
 def test_full_size_properties(ctx):
     """8192 x 8192 (the benchmark shape): size-independent properties instead of the oracle.
     Swapping the images transposes the match set; matching an image with itself is the identity

@@ -201,13 +201,132 @@ def test_loss_follows_std_max_nan_rule(oracle):
     assert np.isnan(oracle.loss(K, [0.0, 0.0], [0.0, 0.0], [0.0, 0.0, 0.0], np.eye(4)))
 
 
-def test_ransac_against_numpy_restatement(oracle):
-    """Independent evaluation with LAPACK (svd, lstsq) of fit + triangulate + loss: counts agree
-    for hypotheses whose errors are not within rounding of the threshold (all of them here)."""
+def test_triangulation_is_as_accurate_as_lapack(oracle):
+    """The restated column-pivoted QR solve against an extended-precision solution: its error stays
+    within the same multiple of cond * eps as LAPACK's own (near-parallel rays and small residuals
+    included), where the normal equations lose another factor of cond."""
+    rng = np.random.default_rng(33)
+    L = np.longdouble
+
+    def exact(a, b, T):
+        a, b, T = a.astype(L), b.astype(L), T.astype(L)
+        aa, ab, bb, aT, bT = a @ a, a @ b, b @ b, a @ T, b @ T
+        det = aa * bb - ab * ab
+        return np.array([(ab * bT - bb * aT) / det, (aa * bT - ab * aT) / det])
+
+    worst = dict(qr=0.0, ne=0.0, lapack=0.0)
+    for i in range(3000):
+        a, T = rng.standard_normal(3), rng.standard_normal(3)
+        b = np.array([rng.standard_normal(), rng.standard_normal(), 1.0])
+        if i % 3 == 0:
+            a = -(b * rng.uniform(0.5, 2) + 1e-2 * rng.standard_normal(3))          # near-parallel rays
+        if i % 3 == 1:
+            T = -a * rng.uniform(1, 5) + b * rng.uniform(1, 5) + 1e-4 * rng.standard_normal(3)  # small residual
+        A = np.stack([-a, b], axis=1)
+        ex = exact(a, b, T)
+        scale = float(np.abs(ex).max()) * np.linalg.cond(A) * 2.2e-16
+        for name, v in (("qr", oracle.triangulate(a, b, T)), ("ne", oracle.triangulate_normal_equations(a, b, T)),
+                        ("lapack", np.linalg.lstsq(A, T, rcond=None)[0])):
+            worst[name] = max(worst[name], float(np.abs(v - ex).max()) / scale)
+    assert worst["qr"] < 3 * worst["lapack"] + 10
+    assert worst["ne"] > 3 * worst["qr"]
+
+
+def lapack_cells(x, y, K, pose12):
+    """Depth (before the float cast) and default loss of every (hypothesis, correspondence) cell with
+    LAPACK doing the 3x2 least squares (batched SVD) and numpy the loss: an evaluation that shares no
+    code and no operation order with the restatement."""
+    n = len(x)
+    xh = np.concatenate([x, np.ones((n, 1))], axis=1)
+    yh = np.concatenate([y, np.ones((n, 1))], axis=1)
+    H = len(pose12)
+    lam, err = np.zeros((H, n)), np.zeros((H, n))
+    o1, o2 = (xh @ K.T)[:, :2], (yh @ K.T)[:, :2]
+    for h in range(H):
+        R, T = pose12[h, :9].reshape(3, 3), pose12[h, 9:]
+        A = np.stack([-(xh @ R.T), yh], axis=2)  # (n, 3, 2)
+        U, S, Vt = np.linalg.svd(A, full_matrices=False)
+        lsq = np.einsum("nji,nj->ni", Vt, np.einsum("nij,i->nj", U, T) / S)
+        lam[h] = lsq[:, 0]
+        P = lsq[:, 0].astype(np.float32).astype(np.float64)[:, None] * xh  # eightPoint.cpp:365,368
+        with np.errstate(all="ignore"):
+            p1 = P @ K.T
+            e1 = ((p1[:, :2] / p1[:, 2:3] - o1) ** 2).sum(axis=1)
+            q = (P @ R.T + T) @ K.T
+            e2 = ((q[:, :2] / q[:, 2:3] - o2) ** 2).sum(axis=1)
+        err[h] = np.where(e1 < e2, e2, e1)
+    return lam, err
+
+
+def count_disagreements(oracle, tv, S, thr, method=0):
+    """(cells, inlier decisions that differ from LAPACK's, depths that round to another float, the largest
+    |error - threshold| / threshold among the differing decisions)."""
+    pose12, _ = oracle.fit_hypotheses(tv["x"], tv["y"], S)
+    lam_l, err_l = lapack_cells(tv["x"], tv["y"], tv["K"], pose12)
+    lam, err = oracle.score_cells(tv["x"], tv["y"], tv["K"], pose12, method=method)
+    with np.errstate(all="ignore"):
+        flip = (err < thr) != (err_l < thr)
+    off = float(np.abs(err[flip] - thr).max() / thr) if flip.any() else 0.0
+    return lam.size, int(flip.sum()), int((lam.astype(np.float32) != lam_l.astype(np.float32)).sum()), off
+
+
+# A depth that LAPACK and the restatement round to different floats (eightPoint.cpp:365) moves the camera-2
+# reprojection by at most one float ulp of the depth times the parallax: decisions may differ only for
+# errors this close (relatively) to the threshold.
+DECISION_BAND = 1e-4
+
+
+def test_ransac_decisions_against_lapack(oracle):
+    """Twenty seeded pairs (15-80 % inliers, 400-3250 correspondences, 48 sample rows each) and one of the
+    benchmark's shape (5000 correspondences, 15 % inliers, 256 rows): every (hypothesis, correspondence)
+    inlier decision of the restatement against a LAPACK evaluation.  No decision differs outside the
+    stated band of the threshold; the counts and the depth-rounding mismatches are printed (pytest -s)."""
+    cases = [(s, 400 + 150 * s, 48, (0.15, 0.3, 0.5, 0.8)[s % 4]) for s in range(20)] + [(100, 5000, 256, 0.15)]
+    cells = flips = depth_mismatch = 0
+    for seed, n, H, ratio in cases:
+        tv = synth.two_view(n, inlier_ratio=ratio, seed=1000 + seed)
+        S = synth.sample_table(n, H, seed=2000 + seed)
+        c, f, d, off = count_disagreements(oracle, tv, S, 1.0)
+        assert off <= DECISION_BAND, (seed, off)
+        cells, flips, depth_mismatch = cells + c, flips + f, depth_mismatch + d
+        # and the per-row counts of the whole RANSAC call are those decisions added up
+        if seed % 5 == 0:
+            r = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, adaptive=False)
+            pose12, _ = oracle.fit_hypotheses(tv["x"], tv["y"], S)
+            _, err_l = lapack_cells(tv["x"], tv["y"], tv["K"], pose12)
+            assert np.array_equal(r["counts"], (err_l < 1.0).sum(axis=1))
+    print(f"cells {cells}, differing decisions {flips}, depths rounding to another float {depth_mismatch}")
+    assert cells > 3_000_000 and flips == 0  # observed: 0 and 0 in 3 032 000 cells
+
+
+def test_ransac_decisions_far_scene(oracle):
+    """Depths of 200-5000 baselines (rays a few 1e-4 rad apart: the 3x2 system has a condition number in the
+    thousands).  The QR solve still rounds to LAPACK's float depth in all but a few cells per million; the
+    normal equations, which square the condition number, miss it in a few per thousand.  Decisions: none
+    differs outside the band for either."""
+    cells = 0
+    flips, depth_mismatch = [0, 0], [0, 0]
+    for seed in range(4):
+        tv = synth.two_view(2000, inlier_ratio=0.7, seed=3000 + seed, depth=(200.0, 5000.0), max_rot_deg=3.0, noise_px=0.3)
+        S = synth.sample_table(2000, 64, seed=4000 + seed)
+        for method in (0, 1):
+            c, f, d, off = count_disagreements(oracle, tv, S, 1.0, method)
+            assert off <= DECISION_BAND, (seed, method, off)
+            flips[method] += f
+            depth_mismatch[method] += d
+        cells += c
+    print(f"cells {cells}: QR {flips[0]} decisions / {depth_mismatch[0]} depths differ, "
+          f"normal equations {flips[1]} / {depth_mismatch[1]}")
+    assert depth_mismatch[0] <= cells * 2e-5          # observed 1 in 512 000
+    assert depth_mismatch[1] >= 20 * max(depth_mismatch[0], 1)  # observed 1197
+
+
+def test_fit_against_lapack(oracle):
+    """The fitted (R, T) factorises LAPACK's null vector of the 8x9 system (up to scale and the rank-2
+    projection), for 40 sample rows."""
     tv = synth.two_view(120, inlier_ratio=0.6, seed=21)
-    x, y, K = tv["x"], tv["y"], tv["K"]
+    x, y = tv["x"], tv["y"]
     S = synth.sample_table(120, 40, seed=22)
-    r = oracle.ransac(x, y, K, S, max_sq_err=1.0, adaptive=False)
     xh = np.concatenate([x, np.ones((120, 1))], axis=1)
     yh = np.concatenate([y, np.ones((120, 1))], axis=1)
     pose12, _ = oracle.fit_hypotheses(x, y, S)
@@ -217,20 +336,11 @@ def test_ransac_against_numpy_restatement(oracle):
         R, T = pose12[h, :9].reshape(3, 3), pose12[h, 9:]
         Tx = np.array([[0, -T[2], T[1]], [T[2], 0, -T[0]], [-T[1], T[0], 0]])
         E2 = Tx @ R
-        # the restatement's (R, T) factorises the LAPACK null vector up to scale and the rank-2 projection
         Ue, Se, Vte = np.linalg.svd(E)
         Eproj = Ue @ np.diag([1, 1, 0]) @ Vte
         c = (E2 * Eproj).sum() / (Eproj * Eproj).sum()
         assert np.allclose(E2, c * Eproj, atol=1e-6)
-        cnt = 0
-        for k in range(120):
-            lam = np.linalg.lstsq(np.stack([-(R @ xh[k]), yh[k]], axis=1), T, rcond=None)[0]
-            P = np.float64(np.float32(lam[0])) * xh[k]
-            e1 = np.sum(((K @ P)[:2] / (K @ P)[2] - (K @ xh[k])[:2]) ** 2)
-            q = K @ (R @ P + T)
-            e2 = np.sum((q[:2] / q[2] - (K @ yh[k])[:2]) ** 2)
-            cnt += max(e1, e2) < 1.0
-        assert cnt == r["counts"][h]
+        assert abs(np.linalg.det(R) - 1) < 1e-9 and abs(np.linalg.norm(T) - 1) < 1e-9
 
 
 def test_adaptive_cap_formula(oracle):

@@ -40,6 +40,31 @@ def test_ransac_stress_ratio(ctx, oracle):
     assert got["iterations"] == 2048
 
 
+def test_benchmark_shape_against_restatement(ctx, oracle):
+    """One pair of the benchmark's RANSAC shape at full size (20 000 correspondences, 15 % inliers, 4096
+    sample rows, the benchmark's generator): per-row inlier counts and error sums (RANSAC.cpp:213-221), the
+    winner and its inlier list are those of the CPU restatement, bit for bit, with the pre-test on and off."""
+    tv = synth.two_view(20000, inlier_ratio=0.15, seed=[0, 0])
+    S = synth.sample_table(20000, 4096, seed=[7, 0, 0])
+    exp = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    assert exp["iterations"] == 4096
+    for flt in (1, 0):
+        ctx.set_option("ransac_filter", flt)
+        try:
+            got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        finally:
+            ctx.set_option("ransac_filter", 1)
+        assert_same_run(got, exp, pose_tol=0.0)
+        assert np.array_equal(got["toterr"].view(np.uint64), exp["toterr"].view(np.uint64))
+    # the batch entry point (slices of rows, no per-row outputs) keeps the same winner
+    b = ctx.ransac_batch(np.array([0, 20000], np.int64), tv["x"], tv["y"], tv["K"], S, 4096, max_sq_err=1.0,
+                         success_prob=0.999, adaptive=True)
+    best = b.best()
+    assert best["best_h"][0] == exp["best_h"] and best["count"][0] == len(exp["inliers"])
+    assert np.array_equal(b.inliers()[1], exp["inliers"])
+    b.close()
+
+
 def test_poses_bit_identical_to_restatement(ctx, oracle):
     tv = synth.two_view(500, inlier_ratio=0.6, seed=9)
     S = synth.sample_table(500, 512, seed=10)
