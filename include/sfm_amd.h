@@ -201,6 +201,21 @@ int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, int n, const
                     int *best_hyp_out, double *pose_out,
                     int32_t *counts_out, double *toterr_out, int *iterations_out);
 
+/* sfm_ransac_pair for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments,
+ * same kernels, same results as sfm_ransac_pair, but all device work space is a fixed array that the
+ * library's code object carries (about 3.4 MB per GPU, held until the process ends), so the call performs
+ * no hipMalloc, no hipFree and creates no events.  Limits: n <= 16384 correspondences and
+ * n_hyp <= 8192 sample rows; beyond them the call returns SFM_ERR_CAPACITY and does nothing.  All calls
+ * on one GPU share that array: calls that overlap in time on one GPU (two contexts or two host threads)
+ * race; successive calls are safe. */
+int sfm_ransac_pair_static(sfm_ctx *ctx, const double *x, const double *y, int n, const double *K,
+                           const int32_t *samples, int n_hyp, int min_n,
+                           double max_squared_error, double success_prob, int adaptive, int loss,
+                           int32_t *inliers_out, int capacity, int *count_out,
+                           int *best_hyp_out, double *pose_out,
+                           int32_t *counts_out, double *toterr_out, int *iterations_out);
+
 /* Fit only: pose12_out[n_hyp][12] = R row-major (9) then T (3) per sample row.
  * Replaces the fit half of eightPointAlgorithmFromSubset (eightPoint.cpp:233-344). */
 int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n,

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
     "sfm_match_result_destroy",
-    "sfm_ransac_pair", "sfm_eight_point_fit", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
+    "sfm_ransac_pair", "sfm_ransac_pair_static", "sfm_eight_point_fit", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
     L.sfm_match_result_destroy.restype = None
     L.sfm_ransac_pair.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, f64, f64, i32, i32, vp, i32, P(i32),
                                   P(i32), vp, vp, vp, P(i32)]
+    L.sfm_ransac_pair_static.argtypes = L.sfm_ransac_pair.argtypes
     L.sfm_eight_point_fit.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     L.sfm_eight_point_algorithm.argtypes = [vp, vp, vp, i32, vp, vp]
     L.sfm_ransac_batch_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
@@ -223,10 +224,11 @@ class Context:
 
     # ---- RANSAC ---------------------------------------------------------------------------
     def ransac_pair(self, x, y, K, samples, max_sq_err=10.0, success_prob=0.99, adaptive=True, min_n=8,
-                    loss=LOSS_REPROJECTION, per_row=True):
+                    loss=LOSS_REPROJECTION, per_row=True, static_workspace=False):
         """solve::RANSAC for one pair.  per_row=False leaves out the per-hypothesis counts and error sums
         (the reference does not return them); the library then scores rows in growing slices and stops
-        where the adaptive cap stops the reference's loop."""
+        where the adaptive cap stops the reference's loop.  static_workspace=True calls the entry point
+        that allocates nothing (sfm_ransac_pair_static)."""
         x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
         y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
         if len(x) != len(y):  # RANSAC.cpp:148
@@ -240,10 +242,10 @@ class Context:
         counts = np.zeros(max(H, 1), np.int32) if per_row else None
         toterr = np.zeros(max(H, 1), np.float64) if per_row else None
         cnt, best, iters = C.c_int(0), C.c_int(-1), C.c_int(0)
-        self.check(lib().sfm_ransac_pair(self._h, _ptr(x), _ptr(y), n, _ptr(Kc), _ptr(samples), H, min_n,
-                                         max_sq_err, success_prob, int(bool(adaptive)), loss, _ptr(inl), max(n, 1),
-                                         C.byref(cnt), C.byref(best), _ptr(pose), _ptr(counts), _ptr(toterr),
-                                         C.byref(iters)))
+        entry = lib().sfm_ransac_pair_static if static_workspace else lib().sfm_ransac_pair
+        self.check(entry(self._h, _ptr(x), _ptr(y), n, _ptr(Kc), _ptr(samples), H, min_n,
+                         max_sq_err, success_prob, int(bool(adaptive)), loss, _ptr(inl), max(n, 1),
+                         C.byref(cnt), C.byref(best), _ptr(pose), _ptr(counts), _ptr(toterr), C.byref(iters)))
         return dict(inliers=inl[:cnt.value].copy(), best_h=best.value, pose=pose.reshape(4, 4, order="F").copy(),
                     counts=counts[:H].copy() if per_row else None, toterr=toterr[:H].copy() if per_row else None,
                     iterations=iters.value)

@@ -44,6 +44,9 @@ struct sfm_ctx {
 void sfm_chain_scratch_free(sfm_ctx *ctx);
 void sfm_pair_batch_free(sfm_ctx *ctx);
 void sfm_pair_match_free(sfm_ctx *ctx);
+// Per-device set-up of the RANSAC entry point that allocates nothing (address of its static workspace);
+// called by sfm_ctx_create with the device current.
+int sfm_ransac_static_setup(int device);
 
 #define SFM_FAIL(ctx, code, ...)                                   \
     do {                                                           \
@@ -63,13 +66,16 @@ void sfm_pair_match_free(sfm_ctx *ctx);
         }                                                                               \
     } while (0)
 
-// Grow-only device buffer.
+// Grow-only device buffer.  A `fixed` buffer is a slice of memory that somebody else owns (the static
+// workspace of the entry point that allocates nothing): it never grows and is never freed.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool fixed = false;
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+        if (fixed) return hipErrorOutOfMemory;
         if (p) {
             hipError_t e = hipFree(p);
             p = nullptr;
@@ -87,7 +93,7 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p && !fixed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
     }

@@ -29,6 +29,11 @@ extern "C" int sfm_ctx_create(int device, sfm_ctx **ctx_out)
         sfm_ctx_destroy(c);
         return SFM_ERR_HIP;
     }
+    const int rc = sfm_ransac_static_setup(device);
+    if (rc != SFM_OK) {
+        sfm_ctx_destroy(c);
+        return rc;
+    }
     *ctx_out = c;
     return SFM_OK;
 }
@@ -67,10 +72,11 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
 {
     if (!ctx || !key) return SFM_ERR_INVALID_ARG;
     if (!strcmp(key, "cand_capacity")) {
-        if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "cand_capacity must be >= 0");
+        if (value < 0 || value > 0x7FFFFFFF) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "cand_capacity must be in [0, 2^31)");
         ctx->cand_capacity = value;
     } else if (!strcmp(key, "pairs_per_launch")) {
-        if (value < 1) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "pairs_per_launch must be >= 1");
+        // (a chunk's pairs are one grid dimension of several kernels)
+        if (value < 1 || value > 65535) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "pairs_per_launch must be in [1, 65535]");
         ctx->pairs_per_launch = value;
     } else if (!strcmp(key, "hyps_per_launch")) {
         if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "hyps_per_launch must be >= 0");

@@ -1460,8 +1460,10 @@ static bool pretest_applies(const sfm_ctx *ctx, const double *K, int loss)
 static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
                       const double *K, const int32_t *samples, int n_hyp, double maxSqErr, double successProb,
                       int adaptive, int loss, bool on_device, bool fit_only, sfm_ransac_batch **batch_inout,
-                      bool phased = true)
+                      bool phased = true, bool no_alloc = false)
 {
+    // no_alloc: the batch's buffers are fixed slices of the static workspace; nothing here may allocate (no
+    // split scoring, whose buffer grows with the launch; no kernel timing, whose events are created on demand).
     if (!ctx || !batch_inout) return SFM_ERR_INVALID_ARG;
     if (n_pairs < 0 || n_hyp < 0 || (n_pairs > 0 && !corr_offsets))
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: bad sizes");
@@ -1496,9 +1498,9 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     b->total = total;
     b->scored = false;
     b->refitted = false;
-    if (n_pairs > 0) b->corrOffHost.assign(corr_offsets, corr_offsets + n_pairs + 1);
+    if (n_pairs > 0) b->corrOffHost.assign(corr_offsets, corr_offsets + n_pairs + 1); // (capacity reserved at set-up for the static batch)
     else b->corrOffHost.assign(1, 0);
-    sfm_span_reset(ctx, 1);
+    if (!no_alloc) sfm_span_reset(ctx, 1);
     hipStream_t st = ctx->stream;
     const size_t PH = (size_t)(n_pairs ? n_pairs : 1) * (size_t)(n_hyp ? n_hyp : 1);
     const size_t P1 = (size_t)(n_pairs ? n_pairs : 1);
@@ -1584,7 +1586,9 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.active = b->active.as<int>();
     g.maxIter = b->maxIter.as<int>();
     SFM_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)b->active.p, 1, (size_t)n_pairs, st));
-    std::vector<int> bounds{0};
+    int bounds[40]; // slices grow by a factor of four: at most 17 of them below 2^31 rows
+    int nBounds = 0;
+    bounds[nBounds++] = 0;
     if (phased && adaptive && !fit_only) {
         // The first slice is as small as its launch can be made efficient: 256 rows (one block of rows
         // per pair; with most correspondences inliers the cap falls below that at once) when the scoring
@@ -1594,19 +1598,19 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         // divides evenly).
         const int64_t fill = 8 * (int64_t)ctx->n_cus;
         int64_t h = 256 * std::max<int64_t>(1, (fill + n_pairs - 1) / n_pairs);
-        if (split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
+        if (!no_alloc && split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
         if (ctx->hyps_per_launch > 0) h = 64 * ((ctx->hyps_per_launch + 63) / 64); // caller's first slice
-        while (h < n_hyp) {
-            bounds.push_back((int)h);
+        while (h < n_hyp && nBounds < 38) {
+            bounds[nBounds++] = (int)h;
             h *= 4;
         }
     }
-    bounds.push_back(n_hyp);
+    bounds[nBounds++] = n_hyp;
     if (n_hyp > 0) // poses of rows that are never fitted must not be read as garbage
         SFM_HIP(ctx, hipMemsetAsync(b->pose12.p, 0, (size_t)n_pairs * n_hyp * 12 * sizeof(double), st));
     if (!fit_only && total > 0)
         hipLaunchKernelGGL(ransac_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, total);
-    for (size_t ph = 0; ph + 1 < bounds.size(); ph++) {
+    for (int ph = 0; ph + 1 < nBounds; ph++) {
         g.hBegin = bounds[ph];
         g.hEnd = bounds[ph + 1];
         const int rows = g.hEnd - g.hBegin;
@@ -1614,8 +1618,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         if (fit_only) continue;
         if (rows > 0) {
             const size_t errBytes = (size_t)rows * (size_t)total * sizeof(double);
-            const int Z = split_factor(ctx, n_pairs, rows, total);
-            SFM_HIP(ctx, sfm_span_begin(ctx, 1));
+            const int Z = no_alloc ? 1 : split_factor(ctx, n_pairs, rows, total);
+            if (!no_alloc) SFM_HIP(ctx, sfm_span_begin(ctx, 1));
             const dim3 grid((rows + 255) / 256, n_pairs, Z);
             const bool pretest = g.filter != 0;
             double *eb = nullptr;
@@ -1638,7 +1642,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                 else
                     hipLaunchKernelGGL(ransac_sum_kernel<16>, dim3((rows + 15) / 16, n_pairs), dim3(SUM_THREADS), 0, st, g, eb);
             }
-            SFM_HIP(ctx, sfm_span_end(ctx, 1));
+            if (!no_alloc) SFM_HIP(ctx, sfm_span_end(ctx, 1));
         }
         hipLaunchKernelGGL(ransac_select_kernel, dim3(n_pairs), dim3(256), 0, st, g);
     }
@@ -1908,4 +1912,148 @@ extern "C" int sfm_eight_point_algorithm(sfm_ctx *ctx, const double *x, const do
     if (rc == SFM_OK) rc = sfm_ransac_batch_refit(b);
     if (rc == SFM_OK) rc = sfm_ransac_batch_refit_fetch(b, pose16_out, nullptr, points_out);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// sfm_ransac_pair for callers that cannot allocate
+// ---------------------------------------------------------------------------------------
+// Same work, same kernels, same results as sfm_ransac_pair, but every device buffer the kernels need
+// beyond the caller's inputs and outputs (device copies of x, y and the sample table, the prepared
+// records, per-row poses, counts and error sums, selection state, inlier flags) is a fixed slice of one
+// file-scope device array, so the call performs no hipMalloc / hipFree and creates no events.  Each GPU
+// holds its own copy of the array (about 3.5 MB) until the process ends; its address on a device is
+// looked up once, when the first context on that device is created.  All calls on one GPU share the
+// array: calls that overlap on one GPU (two contexts, two host threads) race.
+#define SFM_STATIC_MAX_CORR 16384
+#define SFM_STATIC_MAX_HYP 8192
+#define SFM_STATIC_MAX_DEVICES 64
+
+namespace {
+constexpr size_t slice256(size_t bytes) { return (bytes + 255) / 256 * 256; }
+constexpr size_t ST_XY = slice256((size_t)SFM_STATIC_MAX_CORR * sizeof(double2));
+constexpr size_t ST_SAMPLES = slice256((size_t)SFM_STATIC_MAX_HYP * 8 * sizeof(int32_t));
+constexpr size_t ST_REC = slice256((size_t)SFM_STATIC_MAX_CORR * REC_D * sizeof(double));
+constexpr size_t ST_REC32 = slice256(((size_t)20 * ((SFM_STATIC_MAX_CORR + 6) / 4) + 40) * sizeof(float));
+constexpr size_t ST_POSE = slice256((size_t)SFM_STATIC_MAX_HYP * 12 * sizeof(double));
+constexpr size_t ST_COUNTS = slice256((size_t)SFM_STATIC_MAX_HYP * sizeof(int));
+constexpr size_t ST_TOTERR = slice256((size_t)SFM_STATIC_MAX_HYP * sizeof(double));
+constexpr size_t ST_INLIERS = slice256((size_t)SFM_STATIC_MAX_CORR * sizeof(int32_t));
+constexpr size_t ST_FLAGS = slice256((size_t)SFM_STATIC_MAX_CORR);
+constexpr size_t ST_BLK = slice256((size_t)((SFM_STATIC_MAX_CORR + 255) / 256) * sizeof(int));
+constexpr size_t ST_SMALL = 256; // per-pair scalars of a one-pair batch, two offsets
+constexpr size_t STATIC_SCRATCH_BYTES = 2 * ST_XY + ST_SAMPLES + ST_REC + ST_REC32 + ST_POSE + ST_COUNTS + ST_TOTERR +
+                                        ST_INLIERS + ST_FLAGS + ST_BLK + 9 * ST_SMALL;
+} // namespace
+
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+// Host side: where `scratch` lives on each device (the array's name is no device address in host code),
+// and a batch per device whose buffers are slices of it.
+static unsigned char *g_scratchPtr[SFM_STATIC_MAX_DEVICES];
+static sfm_ransac_batch *g_staticBatch[SFM_STATIC_MAX_DEVICES];
+
+int sfm_ransac_static_setup(int device)
+{
+    if (device < 0 || device >= SFM_STATIC_MAX_DEVICES) return SFM_OK; // such a device has no static entry point
+    if (g_scratchPtr[device]) return SFM_OK;
+    void *ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return SFM_ERR_HIP;
+    sfm_ransac_batch *b = new (std::nothrow) sfm_ransac_batch();
+    if (!b) return SFM_ERR_OOM;
+    unsigned char *at = static_cast<unsigned char *>(ptr);
+    auto slice = [&](DevBuf &d, size_t bytes) {
+        d.p = at;
+        d.cap = bytes;
+        d.fixed = true;
+        at += bytes;
+    };
+    slice(b->x, ST_XY);
+    slice(b->y, ST_XY);
+    slice(b->samples, ST_SAMPLES);
+    slice(b->rec, ST_REC);
+    slice(b->rec32, ST_REC32);
+    slice(b->pose12, ST_POSE);
+    slice(b->counts, ST_COUNTS);
+    slice(b->toterr, ST_TOTERR);
+    slice(b->inliers, ST_INLIERS);
+    slice(b->inlFlag, ST_FLAGS);
+    slice(b->inlBlk, ST_BLK);
+    slice(b->corrOff, ST_SMALL);
+    slice(b->bestH, ST_SMALL);
+    slice(b->bestCount, ST_SMALL);
+    slice(b->bestErr, ST_SMALL);
+    slice(b->iterations, ST_SMALL);
+    slice(b->inlCount, ST_SMALL);
+    slice(b->inlOff, ST_SMALL);
+    slice(b->active, ST_SMALL);
+    slice(b->maxIter, ST_SMALL);
+    if ((size_t)(at - static_cast<unsigned char *>(ptr)) != STATIC_SCRATCH_BYTES) { // the table above and the size disagree
+        delete b;
+        return SFM_ERR_HIP;
+    }
+    b->corrOffHost.reserve(2);
+    g_staticBatch[device] = b;
+    g_scratchPtr[device] = static_cast<unsigned char *>(ptr);
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_pair_static(sfm_ctx *ctx, const double *x, const double *y, int n, const double *K,
+                                      const int32_t *samples, int n_hyp, int min_n, double max_squared_error,
+                                      double success_prob, int adaptive, int loss, int32_t *inliers_out, int capacity,
+                                      int *count_out, int *best_hyp_out, double *pose_out, int32_t *counts_out,
+                                      double *toterr_out, int *iterations_out)
+{
+    if (!ctx || !count_out) return SFM_ERR_INVALID_ARG;
+    *count_out = 0;
+    if (best_hyp_out) *best_hyp_out = -1;
+    if (iterations_out) *iterations_out = 0;
+    if (n < 0 || n_hyp < 0 || capacity < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: negative size");
+    if (min_n != 8)
+        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "ransac: minN = %d has no kernel (the 8-point model needs exactly 8)", min_n);
+    if (n > SFM_STATIC_MAX_CORR || n_hyp > SFM_STATIC_MAX_HYP)
+        SFM_FAIL(ctx, SFM_ERR_CAPACITY,
+                 "ransac (static workspace): %d correspondences x %d sample rows exceed its fixed size of %d x %d; "
+                 "use sfm_ransac_pair",
+                 n, n_hyp, SFM_STATIC_MAX_CORR, SFM_STATIC_MAX_HYP);
+    if (ctx->device >= SFM_STATIC_MAX_DEVICES || !g_staticBatch[ctx->device])
+        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "ransac (static workspace): not set up on device %d", ctx->device);
+    if (n < min_n) return SFM_OK; // RANSAC.cpp:148-149
+    sfm_ransac_batch *b = g_staticBatch[ctx->device];
+    b->ctx = ctx; // the workspace belongs to the device, whichever context calls
+    const int64_t off[2] = {0, n};
+    int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, max_squared_error, success_prob, adaptive, loss, false, false, &b,
+                        !counts_out && !toterr_out, true);
+    if (rc != SFM_OK) return rc;
+    hipStream_t st = ctx->stream;
+    int32_t bh = -1, bc = 0, it = 0;
+    SFM_HIP(ctx, hipMemcpyAsync(&bh, b->bestH.p, sizeof bh, hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipMemcpyAsync(&bc, b->bestCount.p, sizeof bc, hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipMemcpyAsync(&it, b->iterations.p, sizeof it, hipMemcpyDeviceToHost, st));
+    if (counts_out && n_hyp > 0)
+        SFM_HIP(ctx, hipMemcpyAsync(counts_out, b->counts.p, (size_t)n_hyp * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (toterr_out && n_hyp > 0)
+        SFM_HIP(ctx, hipMemcpyAsync(toterr_out, b->toterr.p, (size_t)n_hyp * sizeof(double), hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipStreamSynchronize(st));
+    if (bc > capacity) SFM_FAIL(ctx, SFM_ERR_CAPACITY, "ransac: inlier capacity too small");
+    double pose12[12];
+    if (bh >= 0 && pose_out)
+        SFM_HIP(ctx, hipMemcpyAsync(pose12, b->pose12.as<double>() + (size_t)bh * 12, sizeof pose12, hipMemcpyDeviceToHost, st));
+    if (bc > 0) {
+        if (!inliers_out) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null inlier buffer");
+        SFM_HIP(ctx, hipMemcpyAsync(inliers_out, b->inliers.p, (size_t)bc * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    SFM_HIP(ctx, hipStreamSynchronize(st));
+    *count_out = bc;
+    if (best_hyp_out) *best_hyp_out = bh;
+    if (iterations_out) *iterations_out = it;
+    if (pose_out) { // 4x4 column-major [R|T; 0 0 0 1]
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) pose_out[r + 4 * c] = (r == c) ? 1.0 : 0.0;
+        if (bh >= 0)
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) pose_out[r + 4 * c] = pose12[3 * r + c];
+                pose_out[r + 12] = pose12[9 + r];
+            }
+    }
+    return SFM_OK;
 }
