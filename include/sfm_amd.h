@@ -348,6 +348,61 @@ int sfm_scale_chain_refit(sfm_ransac_batch *b, const int32_t *corr_track_ids,
                           double *extrinsics_out, double *points3d_out, int32_t *counts_out,
                           double *acc_scale_out);
 
+/* ---- several GPUs of one node ------------------------------------------------
+ * No counterpart in the reference (one process, one pair per call,
+ * submodules/scene.cpp:60).  Pairs are independent, so a pair list is cut
+ * statically -- blocks of 64 consecutive pairs dealt round-robin: pair i belongs
+ * to rank (i / 64) % world -- every GPU matches its share against its own copy of
+ * the image set, and the only exchange is the gather of the match lists to one
+ * rank with RCCL: an all-gather of the per-pair counts, then every rank's list
+ * point to point into one buffer on the root that holds rank 0's lists, then
+ * rank 1's, ... (each in the order of that rank's pairs).
+ */
+typedef struct sfm_comm sfm_comm;
+typedef struct sfm_gathered sfm_gathered;
+/* Host-only helpers of the partition: pairs rank owns; their ascending indices
+ * into the whole list; and, from gathered counts[world][max_owned], where every
+ * pair's list starts in the rank-major buffer and how long it is. */
+int64_t sfm_shard_count(int64_t n_pairs, int rank, int world);
+int sfm_shard_indices(int64_t n_pairs, int rank, int world, int64_t *indices_out);
+int sfm_shard_layout(int64_t n_pairs, int world, const int32_t *counts, int64_t max_owned,
+                     int64_t *starts_out, int32_t *counts_out);
+/* One process per GPU: rank 0 makes an id (128 bytes) and hands it to the other
+ * ranks by any channel; every rank then creates its communicator (collective). */
+int sfm_comm_unique_id(void *id128_out);
+int sfm_comm_create(sfm_ctx *ctx, int rank, int world, const void *id128, sfm_comm **comm_out);
+/* One process that owns n devices: ctxs[i] (one context per device, distinct
+ * devices) becomes rank i. */
+int sfm_comm_create_local(int n, sfm_ctx *const *ctxs, sfm_comm **comms_out);
+int sfm_comm_rank(const sfm_comm *comm, int *rank_out, int *world_out);
+void sfm_comm_destroy(sfm_comm *comm);
+/* Gather (collective over the communicator's ranks): local = this rank's match
+ * result over the pairs sfm_shard_indices gives it, in that order.  Asynchronous
+ * on the context's stream apart from one synchronisation between its two steps.
+ * *gathered_inout is reused across calls (pass a pointer to NULL first). */
+int sfm_match_gather(sfm_comm *comm, sfm_match_result *local, int64_t n_pairs_total, int root,
+                     sfm_gathered **gathered_inout);
+/* The same for all n ranks of a local communicator at once (their calls must be
+ * issued together). */
+int sfm_match_gather_local(int n, sfm_comm *const *comms, sfm_match_result *const *locals,
+                           int64_t n_pairs_total, int root, sfm_gathered **gathered_inout);
+/* sfm_match_batch over n devices of one process: partition, match (the devices
+ * work side by side), gather to rank root.  sets[i] is the image set on rank
+ * i's device (the same images on every device). */
+int sfm_match_batch_multi(int n, sfm_comm *const *comms, const sfm_imageset *const *sets,
+                          const int32_t *pair_list, int64_t n_pairs,
+                          int metric, float threshold, float max_distance_px_squared, int root,
+                          sfm_match_result **results_inout, sfm_gathered **gathered_inout);
+/* Results.  total and per-rank totals (every rank); per pair of the whole list
+ * the start and length of its list in the rank-major buffer (every rank); the
+ * lists themselves, pairs_out[2 * total] (root only; synchronises); device views
+ * (pairs: root only, else NULL; counts[world][max_owned]). */
+int sfm_gathered_total(sfm_gathered *g, int64_t *total_out, int64_t *per_rank_totals_out);
+int sfm_gathered_layout(sfm_gathered *g, int64_t *starts_out, int32_t *counts_out);
+int sfm_gathered_pairs(sfm_gathered *g, int32_t *pairs_out);
+int sfm_gathered_device(sfm_gathered *g, const int32_t **pairs_device, const int32_t **counts_device);
+void sfm_gathered_destroy(sfm_gathered *g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ EXPORTED_SYMBOLS = [
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
     "sfm_match_batch_ratio", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
+    "sfm_shard_count", "sfm_shard_indices", "sfm_shard_layout", "sfm_comm_unique_id", "sfm_comm_create",
+    "sfm_comm_create_local", "sfm_comm_rank", "sfm_comm_destroy", "sfm_match_gather", "sfm_match_gather_local",
+    "sfm_match_batch_multi", "sfm_gathered_total", "sfm_gathered_layout", "sfm_gathered_pairs", "sfm_gathered_device",
+    "sfm_gathered_destroy",
 ]
 
 
@@ -93,7 +97,8 @@ def lib() -> C.CDLL:
     L.sfm_match_result_destroy.restype = None
     L.sfm_ransac_pair.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, f64, f64, i32, i32, vp, i32, P(i32),
                                   P(i32), vp, vp, vp, P(i32)]
-    L.sfm_ransac_pair_static.argtypes = L.sfm_ransac_pair.argtypes
+    if hasattr(L, "sfm_ransac_pair_static"):  # (absent only from older builds used in A/B timing runs)
+        L.sfm_ransac_pair_static.argtypes = L.sfm_ransac_pair.argtypes
     L.sfm_eight_point_fit.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     L.sfm_eight_point_algorithm.argtypes = [vp, vp, vp, i32, vp, vp]
     L.sfm_ransac_batch_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
@@ -115,8 +120,173 @@ def lib() -> C.CDLL:
     L.sfm_scale_chain.argtypes = [vp, i32, vp, vp, vp, vp, vp, f64, i32, vp, vp, vp, vp]
     L.sfm_scale_chain_refit.argtypes = [vp, vp, vp, f64, i32, vp, vp, vp, vp]
     L.sfm_corr_destroy.restype = None
+    if hasattr(L, "sfm_shard_count"):  # (absent only from older builds used in A/B timing runs)
+        L.sfm_shard_count.argtypes = [i64, i32, i32]
+        L.sfm_shard_count.restype = i64
+        L.sfm_shard_indices.argtypes = [i64, i32, i32, vp]
+        L.sfm_shard_layout.argtypes = [i64, i32, vp, i64, vp, vp]
+        L.sfm_comm_unique_id.argtypes = [vp]
+        L.sfm_comm_create.argtypes = [vp, i32, i32, vp, P(vp)]
+        L.sfm_comm_create_local.argtypes = [i32, P(vp), P(vp)]
+        L.sfm_comm_rank.argtypes = [vp, P(i32), P(i32)]
+        L.sfm_comm_destroy.argtypes = [vp]
+        L.sfm_comm_destroy.restype = None
+        L.sfm_match_gather.argtypes = [vp, vp, i64, i32, P(vp)]
+        L.sfm_match_gather_local.argtypes = [i32, P(vp), P(vp), i64, i32, P(vp)]
+        L.sfm_match_batch_multi.argtypes = [i32, P(vp), P(vp), vp, i64, i32, f32, f32, i32, P(vp), P(vp)]
+        L.sfm_gathered_total.argtypes = [vp, P(i64), vp]
+        L.sfm_gathered_layout.argtypes = [vp, vp, vp]
+        L.sfm_gathered_pairs.argtypes = [vp, vp]
+        L.sfm_gathered_device.argtypes = [vp, P(vp), P(vp)]
+        L.sfm_gathered_destroy.argtypes = [vp]
+        L.sfm_gathered_destroy.restype = None
     _lib = L
     return L
+
+
+# ---- several GPUs: the library's static partition and RCCL gather ------------------------------------
+def shard_count(n_pairs: int, rank: int, world: int) -> int:
+    return int(lib().sfm_shard_count(int(n_pairs), int(rank), int(world)))
+
+
+def shard_indices(n_pairs: int, rank: int, world: int) -> np.ndarray:
+    """Ascending indices of the pairs rank owns (blocks of 64 consecutive pairs dealt round-robin)."""
+    out = np.zeros(max(shard_count(n_pairs, rank, world), 1), np.int64)
+    rc = lib().sfm_shard_indices(int(n_pairs), int(rank), int(world), _ptr(out))
+    if rc != OK:
+        raise SfmError(rc, "sfm_shard_indices")
+    return out[:shard_count(n_pairs, rank, world)]
+
+
+def shard_layout(n_pairs: int, world: int, counts: np.ndarray):
+    """counts[world, max_owned] -> (starts int64 [n_pairs], counts int32 [n_pairs]) of the rank-major buffer."""
+    counts = np.ascontiguousarray(counts, np.int32).reshape(world, -1)
+    starts = np.zeros(max(n_pairs, 1), np.int64)
+    cnt = np.zeros(max(n_pairs, 1), np.int32)
+    rc = lib().sfm_shard_layout(int(n_pairs), int(world), _ptr(counts), counts.shape[1], _ptr(starts), _ptr(cnt))
+    if rc != OK:
+        raise SfmError(rc, "sfm_shard_layout")
+    return starts[:n_pairs], cnt[:n_pairs]
+
+
+class Comm:
+    """One rank of an RCCL communicator (sfm_comm_*)."""
+
+    def __init__(self, ctx: "Context", handle):
+        _live.add(self)
+        self.ctx = ctx
+        self._h = handle
+        r, w = C.c_int(0), C.c_int(0)
+        ctx.check(lib().sfm_comm_rank(self._h, C.byref(r), C.byref(w)))
+        self.rank, self.world = r.value, w.value
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = lib().sfm_comm_unique_id(buf)
+        if rc != OK:
+            raise SfmError(rc, "sfm_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def create(cls, ctx: "Context", rank: int, world: int, id128: bytes) -> "Comm":
+        """One process per GPU; collective over all ranks."""
+        h = C.c_void_p()
+        ctx.check(lib().sfm_comm_create(ctx._h, int(rank), int(world), C.create_string_buffer(id128, 128), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def local(cls, ctxs) -> list:
+        """One process that owns several devices: ctxs[i] becomes rank i."""
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c._h for c in ctxs])
+        out = (C.c_void_p * n)()
+        ctxs[0].check(lib().sfm_comm_create_local(n, hs, out))
+        return [cls(ctxs[i], C.c_void_p(out[i])) for i in range(n)]
+
+    def gather(self, result: "MatchResult", n_pairs_total: int, root: int = 0, gathered: "Gathered" = None) -> "Gathered":
+        g = gathered if gathered is not None else Gathered(self)
+        self.ctx.check(lib().sfm_match_gather(self._h, result._h, int(n_pairs_total), int(root), C.byref(g._h)))
+        g.n_total, g.root = int(n_pairs_total), int(root)
+        return g
+
+    def close(self):
+        if self._h:
+            lib().sfm_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Gathered:
+    """Match lists of a sharded pair list on the root rank (sfm_gathered_*): rank-major payload."""
+
+    def __init__(self, comm: Comm):
+        _live.add(self)
+        self.comm = comm
+        self.ctx = comm.ctx
+        self._h = C.c_void_p()
+        self.n_total = 0
+        self.root = 0
+
+    def total(self) -> int:
+        t = C.c_int64(0)
+        self.ctx.check(lib().sfm_gathered_total(self._h, C.byref(t), None))
+        return t.value
+
+    def per_rank_totals(self) -> np.ndarray:
+        t = C.c_int64(0)
+        out = np.zeros(self.comm.world, np.int64)
+        self.ctx.check(lib().sfm_gathered_total(self._h, C.byref(t), _ptr(out)))
+        return out
+
+    def layout(self):
+        """(starts int64 [n_total], counts int32 [n_total]): pair p owns pairs()[starts[p] : starts[p] + counts[p]]."""
+        starts = np.zeros(max(self.n_total, 1), np.int64)
+        counts = np.zeros(max(self.n_total, 1), np.int32)
+        self.ctx.check(lib().sfm_gathered_layout(self._h, _ptr(starts), _ptr(counts)))
+        return starts[:self.n_total], counts[:self.n_total]
+
+    def pairs(self) -> np.ndarray:
+        n = self.total()
+        out = np.zeros((max(n, 1), 2), np.int32)
+        self.ctx.check(lib().sfm_gathered_pairs(self._h, _ptr(out)))
+        return out[:n]
+
+    def close(self):
+        if self._h:
+            lib().sfm_gathered_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def match_batch_multi(comms, sets, pair_list, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE, root=0,
+                      results=None, gathered=None):
+    """sfm_match_batch_multi: one process, len(comms) devices.  Returns (results, gathered) lists (reusable)."""
+    n = len(comms)
+    pl = np.ascontiguousarray(pair_list, np.int32).reshape(-1, 2)
+    results = results if results is not None else [MatchResult(c.ctx) for c in comms]
+    gathered = gathered if gathered is not None else [Gathered(c) for c in comms]
+    ch = (C.c_void_p * n)(*[c._h for c in comms])
+    sh = (C.c_void_p * n)(*[s._h for s in sets])
+    rh = (C.c_void_p * n)(*[r._h for r in results])
+    gh = (C.c_void_p * n)(*[g._h for g in gathered])
+    comms[0].ctx.check(lib().sfm_match_batch_multi(n, ch, sh, _ptr(pl), len(pl), metric, threshold, max_dist_sq, root, rh, gh))
+    for i in range(n):
+        results[i]._h = C.c_void_p(rh[i])
+        results[i].n_pairs = shard_count(len(pl), i, n)
+        gathered[i]._h = C.c_void_p(gh[i])
+        gathered[i].n_total, gathered[i].root = len(pl), root
+    return results, gathered
 
 
 def _chain_outputs(S, n_tracks):

@@ -1,0 +1,402 @@
+// Multi-GPU layer of libsfm_amd.so: static partition of an image-pair list over the GPUs of one node
+// and the gather of the per-GPU match lists to one of them with RCCL over xGMI.
+//
+// The reference is a single process that matches one pair per call (submodules/scene.cpp:60); pairs
+// read only their own two images, so a pair list shards with no exchange inside the data path.  The one
+// exchange is the gather of results.  Match lists have variable length, so it runs in two steps:
+//   1. ncclAllGather of the per-pair match counts (every rank pads its counts to the largest share) and
+//      of the per-rank totals;
+//   2. the lists themselves, point to point: every other rank ncclSend's its list to the root, the root
+//      posts all ncclRecv's in one group, each straight into its place in one rank-major buffer.  On an
+//      8-GPU MI355X node every peer has its own xGMI link to the root, so the transfers run side by side
+//      (no ring).
+// Two ways to drive it: one process per GPU (sfm_comm_create from a broadcast id; sfm_match_gather), or
+// one process that owns several devices (sfm_comm_create_local; sfm_match_gather_local /
+// sfm_match_batch_multi), where the calls of all ranks are issued inside one RCCL group.
+#include "common.h"
+#include "match_types.h"
+
+#include <rccl/rccl.h>
+
+#define SHARD_BLOCK 64 // consecutive pairs dealt to one rank (they share an image in an exhaustive list)
+
+struct sfm_comm {
+    sfm_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+struct sfm_gathered {
+    sfm_comm *comm = nullptr;
+    int64_t n_total = 0;   // pairs of the whole list
+    int64_t max_owned = 0; // largest share of a rank
+    int root = 0;
+    DevBuf countsMine, countsAll, totalsMine, totalsAll, payload;
+    std::vector<int64_t> totals;  // per rank, host (valid on every rank)
+    std::vector<int32_t> countsHost; // [world][max_owned], host, filled on demand
+    bool countsFetched = false;
+    int64_t total = 0; // sum of totals
+};
+
+#define SFM_NCCL(ctx, expr)                                                                       \
+    do {                                                                                          \
+        ncclResult_t _r = (expr);                                                                 \
+        if (_r != ncclSuccess)                                                                    \
+            SFM_FAIL(ctx, SFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- static partition -------------------------------------------------------------------------
+// Blocks of SHARD_BLOCK consecutive pairs are dealt round-robin: pair i belongs to rank
+// (i / SHARD_BLOCK) % world.  Shares differ by at most one block.
+extern "C" int64_t sfm_shard_count(int64_t n_pairs, int rank, int world)
+{
+    if (n_pairs <= 0 || world <= 0 || rank < 0 || rank >= world) return 0;
+    const int64_t blocks = (n_pairs + SHARD_BLOCK - 1) / SHARD_BLOCK;
+    const int64_t mine = blocks / world + ((blocks % world) > rank ? 1 : 0); // blocks of this rank
+    int64_t n = mine * SHARD_BLOCK;
+    if (mine > 0 && (blocks - 1) % world == rank) n -= blocks * SHARD_BLOCK - n_pairs; // the last block may be short
+    return n;
+}
+
+extern "C" int sfm_shard_indices(int64_t n_pairs, int rank, int world, int64_t *indices_out)
+{
+    if (n_pairs < 0 || world <= 0 || rank < 0 || rank >= world || (!indices_out && n_pairs > 0)) return SFM_ERR_INVALID_ARG;
+    int64_t k = 0;
+    for (int64_t b = rank; b * SHARD_BLOCK < n_pairs; b += world)
+        for (int64_t i = b * SHARD_BLOCK; i < std::min<int64_t>(n_pairs, (b + 1) * SHARD_BLOCK); i++) indices_out[k++] = i;
+    return SFM_OK;
+}
+
+// Where the gathered lists lie: the buffer holds rank 0's lists, then rank 1's, ..., each in the order of
+// the rank's own pairs.  counts[world][max_owned] are the gathered per-pair counts.  starts_out /
+// counts_out (either may be NULL) are indexed by the pair's position in the whole list.
+extern "C" int sfm_shard_layout(int64_t n_pairs, int world, const int32_t *counts, int64_t max_owned, int64_t *starts_out,
+                                int32_t *counts_out)
+{
+    if (n_pairs < 0 || world <= 0 || (n_pairs > 0 && !counts)) return SFM_ERR_INVALID_ARG;
+    int64_t run = 0;
+    for (int r = 0; r < world; r++) {
+        int64_t k = 0;
+        for (int64_t b = r; b * SHARD_BLOCK < n_pairs; b += world)
+            for (int64_t i = b * SHARD_BLOCK; i < std::min<int64_t>(n_pairs, (b + 1) * SHARD_BLOCK); i++, k++) {
+                if (k >= max_owned) return SFM_ERR_INVALID_ARG;
+                const int32_t c = counts[(size_t)r * max_owned + k];
+                if (starts_out) starts_out[i] = run;
+                if (counts_out) counts_out[i] = c;
+                run += c;
+            }
+    }
+    return SFM_OK;
+}
+
+// ---- communicators ------------------------------------------------------------------------------
+extern "C" int sfm_comm_unique_id(void *id128_out)
+{
+    if (!id128_out) return SFM_ERR_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "the id crosses the C-ABI as 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return SFM_ERR_HIP;
+    memcpy(id128_out, &id, sizeof id);
+    return SFM_OK;
+}
+
+extern "C" int sfm_comm_create(sfm_ctx *ctx, int rank, int world, const void *id128, sfm_comm **comm_out)
+{
+    if (!ctx || !comm_out || !id128 || world < 1 || rank < 0 || rank >= world) return SFM_ERR_INVALID_ARG;
+    *comm_out = nullptr;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    sfm_comm *c = new (std::nothrow) sfm_comm();
+    if (!c) SFM_FAIL(ctx, SFM_ERR_OOM, "comm: host allocation failed");
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        SFM_FAIL(ctx, SFM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r));
+    }
+    *comm_out = c;
+    return SFM_OK;
+}
+
+extern "C" int sfm_comm_create_local(int n, sfm_ctx *const *ctxs, sfm_comm **comms_out)
+{
+    if (n < 1 || !ctxs || !comms_out) return SFM_ERR_INVALID_ARG;
+    std::vector<int> devs(n);
+    std::vector<ncclComm_t> comms(n);
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return SFM_ERR_INVALID_ARG;
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++)
+            if (devs[j] == devs[i]) SFM_FAIL(ctxs[0], SFM_ERR_INVALID_ARG, "comm: device %d is listed twice", devs[i]);
+        comms_out[i] = nullptr;
+    }
+    SFM_NCCL(ctxs[0], ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) {
+        sfm_comm *c = new (std::nothrow) sfm_comm();
+        if (!c) {
+            for (int j = 0; j < n; j++) {
+                if (j < i) delete comms_out[j];
+                (void)ncclCommDestroy(comms[j]);
+            }
+            SFM_FAIL(ctxs[0], SFM_ERR_OOM, "comm: host allocation failed");
+        }
+        c->ctx = ctxs[i];
+        c->comm = comms[i];
+        c->rank = i;
+        c->world = n;
+        comms_out[i] = c;
+    }
+    return SFM_OK;
+}
+
+extern "C" void sfm_comm_destroy(sfm_comm *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int sfm_comm_rank(const sfm_comm *c, int *rank_out, int *world_out)
+{
+    if (!c) return SFM_ERR_INVALID_ARG;
+    if (rank_out) *rank_out = c->rank;
+    if (world_out) *world_out = c->world;
+    return SFM_OK;
+}
+
+// ---- gather ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_counts_kernel(const int64_t *__restrict__ off, int64_t nOwned, int64_t padded,
+                                                            int32_t *__restrict__ counts, int64_t *__restrict__ total)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < padded) counts[i] = i < nOwned ? (int32_t)(off[i + 1] - off[i]) : 0;
+    if (i == 0) *total = nOwned > 0 ? off[nOwned] : 0;
+}
+
+// Step 1 for one rank: counts and total of the local result, and their all-gathers (enqueued; the caller
+// brackets the calls of all its ranks in one RCCL group).
+static int gather_enqueue_counts(sfm_comm *c, sfm_match_result *local, int64_t n_total, int root, sfm_gathered **g_inout)
+{
+    sfm_ctx *ctx = c->ctx;
+    if (!local || !g_inout || n_total < 0 || root < 0 || root >= c->world) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "gather: bad argument");
+    if (local->ctx != ctx) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "gather: the result belongs to another context");
+    const int64_t nOwned = sfm_shard_count(n_total, c->rank, c->world);
+    if (local->n_pairs != nOwned)
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "gather: rank %d of %d owns %lld of %lld pairs, its result holds %d", c->rank, c->world,
+                 (long long)nOwned, (long long)n_total, local->n_pairs);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    sfm_gathered *g = *g_inout;
+    if (!g) {
+        g = new (std::nothrow) sfm_gathered();
+        if (!g) SFM_FAIL(ctx, SFM_ERR_OOM, "gather: host allocation failed");
+        *g_inout = g;
+    }
+    g->comm = c;
+    g->n_total = n_total;
+    g->root = root;
+    g->countsFetched = false;
+    g->max_owned = 0;
+    for (int r = 0; r < c->world; r++) g->max_owned = std::max(g->max_owned, sfm_shard_count(n_total, r, c->world));
+    const size_t padded = (size_t)std::max<int64_t>(g->max_owned, 1);
+    SFM_HIP(ctx, g->countsMine.reserve(padded * sizeof(int32_t)));
+    SFM_HIP(ctx, g->countsAll.reserve(padded * c->world * sizeof(int32_t)));
+    SFM_HIP(ctx, g->totalsMine.reserve(sizeof(int64_t)));
+    SFM_HIP(ctx, g->totalsAll.reserve((size_t)c->world * sizeof(int64_t)));
+    g->totals.assign(c->world, 0);
+    hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, ctx->stream,
+                       local->offsets.as<int64_t>(), nOwned, (int64_t)padded, g->countsMine.as<int32_t>(), g->totalsMine.as<int64_t>());
+    SFM_HIP(ctx, hipGetLastError());
+    SFM_NCCL(ctx, ncclAllGather(g->countsMine.p, g->countsAll.p, padded, ncclInt32, c->comm, ctx->stream));
+    SFM_NCCL(ctx, ncclAllGather(g->totalsMine.p, g->totalsAll.p, 1, ncclInt64, c->comm, ctx->stream));
+    return SFM_OK;
+}
+
+// Between the steps: the totals on the host (the root sizes its buffer and its receives from them).
+static int gather_fetch_totals(sfm_gathered *g)
+{
+    sfm_comm *c = g->comm;
+    sfm_ctx *ctx = c->ctx;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipMemcpyAsync(g->totals.data(), g->totalsAll.p, (size_t)c->world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->total = 0;
+    for (int r = 0; r < c->world; r++) {
+        if (g->totals[r] < 0) SFM_FAIL(ctx, SFM_ERR_HIP, "gather: rank %d reports a negative total", r);
+        g->total += g->totals[r];
+    }
+    if (c->rank == g->root) SFM_HIP(ctx, g->payload.reserve((size_t)std::max<int64_t>(g->total, 1) * sizeof(int2)));
+    return SFM_OK;
+}
+
+// Step 2 for one rank: the root receives every other rank's list into its place, the others send.
+static int gather_enqueue_payload(sfm_gathered *g, sfm_match_result *local)
+{
+    sfm_comm *c = g->comm;
+    sfm_ctx *ctx = c->ctx;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    if (c->rank == g->root) {
+        int64_t base = 0;
+        for (int r = 0; r < c->world; r++) {
+            int2 *dst = g->payload.as<int2>() + base;
+            if (g->totals[r] > 0) {
+                if (r == c->rank)
+                    SFM_HIP(ctx, hipMemcpyAsync(dst, local->pairs.p, (size_t)g->totals[r] * sizeof(int2), hipMemcpyDeviceToDevice, ctx->stream));
+                else
+                    SFM_NCCL(ctx, ncclRecv(dst, (size_t)g->totals[r] * 2, ncclInt32, r, c->comm, ctx->stream));
+            }
+            base += g->totals[r];
+        }
+    } else if (g->totals[c->rank] > 0) {
+        SFM_NCCL(ctx, ncclSend(local->pairs.p, (size_t)g->totals[c->rank] * 2, ncclInt32, g->root, c->comm, ctx->stream));
+    }
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_gather(sfm_comm *c, sfm_match_result *local, int64_t n_pairs_total, int root, sfm_gathered **gathered_inout)
+{
+    if (!c) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = c->ctx;
+    SFM_NCCL(ctx, ncclGroupStart());
+    int rc = gather_enqueue_counts(c, local, n_pairs_total, root, gathered_inout);
+    ncclResult_t e = ncclGroupEnd();
+    if (rc != SFM_OK) return rc;
+    SFM_NCCL(ctx, e);
+    rc = gather_fetch_totals(*gathered_inout);
+    if (rc != SFM_OK) return rc;
+    SFM_NCCL(ctx, ncclGroupStart());
+    rc = gather_enqueue_payload(*gathered_inout, local);
+    e = ncclGroupEnd();
+    if (rc != SFM_OK) return rc;
+    SFM_NCCL(ctx, e);
+    return SFM_OK;
+}
+
+extern "C" int sfm_match_gather_local(int n, sfm_comm *const *comms, sfm_match_result *const *locals, int64_t n_pairs_total, int root,
+                                      sfm_gathered **gathered_inout)
+{
+    if (n < 1 || !comms || !locals || !gathered_inout || !comms[0]) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx0 = comms[0]->ctx;
+    for (int i = 0; i < n; i++)
+        if (!comms[i] || comms[i]->world != n || comms[i]->rank != i) SFM_FAIL(ctx0, SFM_ERR_INVALID_ARG, "gather: comms must be the n ranks of one local communicator, in rank order");
+    int rc = SFM_OK;
+    SFM_NCCL(ctx0, ncclGroupStart());
+    for (int i = 0; i < n && rc == SFM_OK; i++) rc = gather_enqueue_counts(comms[i], locals[i], n_pairs_total, root, &gathered_inout[i]);
+    ncclResult_t e = ncclGroupEnd();
+    if (rc != SFM_OK) return rc;
+    SFM_NCCL(ctx0, e);
+    for (int i = 0; i < n; i++)
+        if ((rc = gather_fetch_totals(gathered_inout[i])) != SFM_OK) return rc;
+    SFM_NCCL(ctx0, ncclGroupStart());
+    for (int i = 0; i < n && rc == SFM_OK; i++) rc = gather_enqueue_payload(gathered_inout[i], locals[i]);
+    e = ncclGroupEnd();
+    if (rc != SFM_OK) return rc;
+    SFM_NCCL(ctx0, e);
+    return SFM_OK;
+}
+
+// ---- accessors --------------------------------------------------------------------------------------
+extern "C" int sfm_gathered_total(sfm_gathered *g, int64_t *total_out, int64_t *per_rank_totals_out)
+{
+    if (!g) return SFM_ERR_INVALID_ARG;
+    if (total_out) *total_out = g->total;
+    if (per_rank_totals_out)
+        for (int r = 0; r < g->comm->world; r++) per_rank_totals_out[r] = g->totals[r];
+    return SFM_OK;
+}
+
+static int gathered_fetch_counts(sfm_gathered *g)
+{
+    if (g->countsFetched) return SFM_OK;
+    sfm_ctx *ctx = g->comm->ctx;
+    const size_t padded = (size_t)std::max<int64_t>(g->max_owned, 1);
+    g->countsHost.resize(padded * g->comm->world);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipMemcpyAsync(g->countsHost.data(), g->countsAll.p, g->countsHost.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->countsFetched = true;
+    return SFM_OK;
+}
+
+// Per pair of the whole list (valid on every rank): where its list starts in the rank-major buffer, and
+// its length.  Either output may be NULL.
+extern "C" int sfm_gathered_layout(sfm_gathered *g, int64_t *starts_out, int32_t *counts_out)
+{
+    if (!g) return SFM_ERR_INVALID_ARG;
+    int rc = gathered_fetch_counts(g);
+    if (rc != SFM_OK) return rc;
+    return sfm_shard_layout(g->n_total, g->comm->world, g->countsHost.data(), std::max<int64_t>(g->max_owned, 1), starts_out, counts_out);
+}
+
+// The gathered lists (root only): pairs_out[2 * total] int32 (i, j), rank-major.  Synchronises.
+extern "C" int sfm_gathered_pairs(sfm_gathered *g, int32_t *pairs_out)
+{
+    if (!g) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = g->comm->ctx;
+    if (g->comm->rank != g->root) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "gather: only the root holds the lists");
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    if (g->total > 0) {
+        if (!pairs_out) return SFM_ERR_INVALID_ARG;
+        SFM_HIP(ctx, hipMemcpyAsync(pairs_out, g->payload.p, (size_t)g->total * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SFM_OK;
+}
+
+extern "C" int sfm_gathered_device(sfm_gathered *g, const int32_t **pairs_device, const int32_t **counts_device)
+{
+    if (!g) return SFM_ERR_INVALID_ARG;
+    if (pairs_device) *pairs_device = g->comm->rank == g->root ? g->payload.as<int32_t>() : nullptr;
+    if (counts_device) *counts_device = g->countsAll.as<int32_t>();
+    return SFM_OK;
+}
+
+extern "C" void sfm_gathered_destroy(sfm_gathered *g)
+{
+    if (!g) return;
+    if (g->comm) {
+        (void)hipSetDevice(g->comm->ctx->device);
+        (void)hipStreamSynchronize(g->comm->ctx->stream);
+    }
+    DevBuf *bufs[] = {&g->countsMine, &g->countsAll, &g->totalsMine, &g->totalsAll, &g->payload};
+    for (DevBuf *d : bufs) d->release();
+    delete g;
+}
+
+// ---- one process, several devices --------------------------------------------------------------------
+// The whole multi-GPU matcher for a caller that owns n devices (the reference is one process): the pair
+// list is cut by sfm_shard_indices, every device matches its share against its own copy of the image set
+// (all launches are asynchronous, so the devices work side by side), and the lists are gathered to
+// ctxs[root]'s device.  results_inout[n] and gathered_inout[n] are reused across calls (pass NULL entries
+// the first time).
+extern "C" int sfm_match_batch_multi(int n, sfm_comm *const *comms, const sfm_imageset *const *sets, const int32_t *pair_list,
+                                     int64_t n_pairs, int metric, float threshold, float max_distance_px_squared, int root,
+                                     sfm_match_result **results_inout, sfm_gathered **gathered_inout)
+{
+    if (n < 1 || !comms || !sets || !results_inout || !gathered_inout || !comms[0] || n_pairs < 0 || (n_pairs > 0 && !pair_list))
+        return SFM_ERR_INVALID_ARG;
+    std::vector<int64_t> idx;
+    std::vector<int32_t> mine;
+    for (int i = 0; i < n; i++) {
+        if (!comms[i] || !sets[i]) return SFM_ERR_INVALID_ARG;
+        sfm_ctx *ctx = comms[i]->ctx;
+        const int64_t cnt = sfm_shard_count(n_pairs, i, n);
+        if (cnt > 0x7FFFFFFF) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "multi: more than 2^31 pairs per device");
+        idx.resize((size_t)cnt);
+        mine.resize((size_t)cnt * 2);
+        int rc = sfm_shard_indices(n_pairs, i, n, idx.data());
+        if (rc != SFM_OK) return rc;
+        for (int64_t k = 0; k < cnt; k++) {
+            mine[2 * k] = pair_list[2 * idx[k]];
+            mine[2 * k + 1] = pair_list[2 * idx[k] + 1];
+        }
+        // (sfm_match_batch copies the list before it returns)
+        rc = sfm_match_batch(ctx, sets[i], mine.data(), (int)cnt, metric, threshold, max_distance_px_squared, &results_inout[i]);
+        if (rc != SFM_OK) return rc;
+    }
+    return sfm_match_gather_local(n, comms, results_inout, n_pairs, root, gathered_inout);
+}

@@ -3,8 +3,11 @@ pairs, and a gather of the per-rank CSR match lists to rank 0.
 
 Pairs are independent (the reference's match() and RANSAC() read only their own two images,
 submodules/scene.cpp:60,261), so the data path has no collective; the only exchange is the final
-gather of results.  With torch.distributed's "nccl" backend that gather runs as concurrent
-point-to-point transfers over xGMI (RCCL); the CPU tests use "gloo".
+gather of results.  Partition and gather are the library's (sfm_shard_*, sfm_comm_*, sfm_match_gather
+in include/sfm_amd.h: RCCL over xGMI, counts by all-gather, lists point to point into a rank-major
+buffer on the root); `partition_pairs` and `library_gather` below call them.  `gather_csr` is the same
+exchange and the same layout written with torch.distributed, for process groups without a GPU (the CPU
+tests run it on "gloo") and as a stand-by on "nccl".
 """
 from __future__ import annotations
 
@@ -17,10 +20,31 @@ def partition_pairs(n_pairs: int, rank: int, world: int, block: int = 64) -> np.
     """Indices (ascending) of the pairs rank owns: blocks of `block` consecutive pairs dealt
     round-robin, so ranks differ by at most one block and consecutive pairs (which share an
     image in an exhaustive list) stay on one GPU."""
+    if block == 64:  # the library's partition (sfm_shard_indices)
+        from . import capi
+        return capi.shard_indices(n_pairs, rank, world)
     if world <= 1:
         return np.arange(n_pairs, dtype=np.int64)
     idx = np.arange(n_pairs, dtype=np.int64)
     return idx[(idx // block) % world == rank]
+
+
+def library_comm(ctx, rank: int, world: int):
+    """The library's communicator for this rank, its id handed round through torch.distributed (any
+    initialised process group will do; world 1 needs none)."""
+    from . import capi
+    if world <= 1:
+        return capi.Comm.create(ctx, 0, 1, capi.Comm.unique_id())
+    import torch.distributed as dist
+    box = [capi.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return capi.Comm.create(ctx, rank, world, box[0])
+
+
+def library_gather(comm, result, n_pairs_total: int, gathered=None):
+    """sfm_match_gather: this rank's result (over partition_pairs(n_pairs_total, rank, world), in that
+    order) to rank 0.  Returns the reusable capi.Gathered (its lists live on rank 0's device)."""
+    return comm.gather(result, n_pairs_total, 0, gathered)
 
 
 def images_for_pairs(n_pairs: int) -> int:
@@ -71,9 +95,13 @@ def gather_csr(counts, payload, n_pairs_total: int, rank: int, world: int, block
     all_counts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(all_counts, mine)
     # step 2: payloads to rank 0, all peers at once, each into its region of one buffer
+    # (Both sides use batched point-to-point operations: on the nccl backend those run on the group's own
+    # communicator, whereas a plain send would open a two-rank communicator that rank 0, which receives in
+    # a batch, never joins, unless the group was created with device_id.)
     if rank != 0:
         if payload.numel() > 0:
-            dist.send(payload.contiguous(), dst=0)
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload.contiguous(), 0)]):
+                req.wait()
         return None
     per_rank_counts = [all_counts[r][:len(owned[r])].cpu().numpy().astype(np.int64) for r in range(world)]
     totals = [int(c.sum()) for c in per_rank_counts]

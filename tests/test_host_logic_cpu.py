@@ -128,3 +128,40 @@ def test_int8_bound_of_the_matcher_is_rigorous():
     spiky[np.arange(200), rng.integers(0, 128, 200)] = 1.0
     _int8_bound_holds(spiky[:100], spiky[100:])
     _int8_bound_holds(sift[:100], rng.standard_normal((100, 128)).astype(np.float32))
+
+
+# ---- the library's static partition and gather layout (host-only entry points) ---------------------
+@pytest.mark.parametrize("n_pairs", [0, 1, 63, 64, 65, 1000, 19900, 499500])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_partition_owns_every_pair_once(n_pairs, world):
+    """sfm_shard_indices / sfm_shard_count: every pair has exactly one owner, shares differ by at most one
+    block of 64, owned indices ascend, consecutive pairs of a block stay together."""
+    from sfm_amd import capi
+    owned = [capi.shard_indices(n_pairs, r, world) for r in range(world)]
+    assert [len(o) for o in owned] == [capi.shard_count(n_pairs, r, world) for r in range(world)]
+    allidx = np.concatenate(owned) if n_pairs else np.zeros(0, np.int64)
+    assert np.array_equal(np.sort(allidx), np.arange(n_pairs))
+    sizes = [len(o) for o in owned]
+    assert max(sizes) - min(sizes) <= 64
+    for r, o in enumerate(owned):
+        assert np.all(np.diff(o) > 0)
+        assert np.all((o // 64) % world == r)
+
+
+def test_gather_layout_against_numpy():
+    """sfm_shard_layout: position of every pair's list in the rank-major buffer, against the same rule
+    written in numpy (rank 0's lists, then rank 1's, ..., each in the order of the rank's pairs)."""
+    from sfm_amd import capi
+    rng = np.random.default_rng(5)
+    for n_pairs, world in [(1000, 8), (64 * 8 + 3, 8), (130, 2), (5, 4), (7, 1)]:
+        owned = [capi.shard_indices(n_pairs, r, world) for r in range(world)]
+        max_owned = max(max(len(o) for o in owned), 1)
+        counts = np.zeros((world, max_owned), np.int32)
+        for r, o in enumerate(owned):
+            counts[r, :len(o)] = rng.integers(0, 50, len(o))
+        starts, cnt = capi.shard_layout(n_pairs, world, counts)
+        run = 0
+        for r, o in enumerate(owned):
+            for k, i in enumerate(o):
+                assert starts[i] == run and cnt[i] == counts[r, k]
+                run += counts[r, k]
