@@ -8,7 +8,17 @@ plus the RANSAC stress shape as a secondary figure.
 One process per GPU (torch.distributed.run launches N of them).  A step is one pass of the
 matcher over this rank's pairs with the image table already resident in HBM; at N > 1 the pair
 list grows with N (weak scaling: 19 900 pairs per GPU), every rank holds the whole table, and the
-step ends with the gather of the match lists to rank 0.  Rank 0 prints one JSON line.
+step ends with the gather of the match lists to rank 0 (the library's RCCL gather).  Rank 0 prints
+one JSON line.
+
+    --strong --images 1000                    a fixed list (1000 images, 499 500 pairs) divided over the N GPUs
+    --strong --images 100 --features 32768    100 images of 32 768 features, 4950 pairs divided over the N GPUs
+
+Besides the headline the line carries, at N = 1: the same matcher in its other regimes (`regimes`:
+fp16 bound, the reference's default threshold 0.5, Gaussian float descriptors, a distribution whose
+unrelated descriptors sit just under the threshold), the RANSAC stress shape as one batch of 10 000
+pairs plus rows at inlier ratios where RANSAC finds its model, the default-run stand-in and the CPU
+restatement timed on a bounded sample.
 """
 from __future__ import annotations
 
@@ -27,9 +37,10 @@ if ROOT not in sys.path:
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of MI355X
 PEAK_I8_TOPS = 5000.0      # dense int8 MFMA peak: the 16x16x64 int8 form takes the cycles of the bf16 16x16x32 form at twice the K
 BOUNDS = {"int8": (1, "i8", PEAK_I8_TOPS), "fp16": (0, "f16", PEAK_F16_TFLOPS)}  # sim_variant, dtype, peak
-PEAK_F64_VEC_TFLOPS = 78.6  # fp64 vector peak
 RANSAC_BYTES_PER_PAIR = 1_082_368  # 20 000 corr * 32 B + 4096 hyp * (96 + 12) B
-RANSAC_FLOPS_PER_EVAL = 92
+# Vector-ALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles each, at the 2.4 GHz behind the
+# data sheet's vector figures (157.3 TFLOP/s fp32 = 1024 SIMDs x 16 lanes x 2 (packed) x 2 (fma) x 2.4 GHz).
+PEAK_VALU_GINST = 1024 * 2.4 / 4
 
 
 def main():
@@ -42,7 +53,15 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.95)
     ap.add_argument("--ratio", type=float, default=None,
                     help="also apply Lowe's second-best ratio test (extension; not the reference's matcher)")
-    ap.add_argument("--ransac-pairs", type=int, default=512, help="pairs per RANSAC batch (the stress shape has 10 000)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the pair list of --images is fixed and divided over the N GPUs")
+    ap.add_argument("--gather", choices=["library", "torch"], default="library",
+                    help="N > 1: gather the match lists with the library's RCCL calls or with torch.distributed")
+    ap.add_argument("--ransac-pairs", type=int, default=10000, help="pairs of the RANSAC batch (the stress shape has 10 000)")
+    ap.add_argument("--ransac-distinct", type=int, default=500,
+                    help="correspondence sets generated on the host; the batch repeats them (separate copies in HBM, "
+                         "every pair with a sample table of its own)")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the matcher's other regimes and the extra RANSAC rows")
     ap.add_argument("--ransac-corr", type=int, default=20000)
     ap.add_argument("--ransac-hyps", type=int, default=4096)
     ap.add_argument("--bound", choices=sorted(BOUNDS), default="int8",
@@ -82,15 +101,22 @@ def main():
     if args.pairs_per_launch > 0:
         ctx.set_option("pairs_per_launch", args.pairs_per_launch)
 
-    # ---- workload: weak scaling, pairs_per_gpu fixed ---------------------------------------
-    pairs_per_gpu = args.images * (args.images - 1) // 2
-    total_pairs = pairs_per_gpu * world
-    n_images = args.images if world == 1 else shard.images_for_pairs(total_pairs)
+    # ---- workload: weak scaling (pairs per GPU fixed) unless --strong (pair list fixed) ------------
+    if args.strong:
+        total_pairs = args.images * (args.images - 1) // 2
+        pairs_per_gpu = (total_pairs + world - 1) // world
+        n_images = args.images
+    else:
+        pairs_per_gpu = args.images * (args.images - 1) // 2
+        total_pairs = pairs_per_gpu * world
+        n_images = args.images if world == 1 else shard.images_for_pairs(total_pairs)
     t0 = time.time()
     desc, pts, counts = synth.image_set(n_images, args.features, seed=2026)
     pair_list = synth.exhaustive_pairs(n_images)[:total_pairs]
     owned = shard.partition_pairs(total_pairs, rank, world)
     my_pairs = np.ascontiguousarray(pair_list[owned])
+    if args.strong:
+        pairs_per_gpu = len(my_pairs)
     imgset = ctx.imageset(counts, desc, pts)
     gen_s = time.time() - t0
 
@@ -100,19 +126,38 @@ def main():
         ctx.synchronize()
         torch.cuda.synchronize()
 
-    # Two result objects: at N > 1 the gather of step k - 1 (RCCL, torch's streams) runs while the
-    # library's stream matches step k.  Every gather is finished before the closing barrier.
+    # Two result objects: at N > 1 the gather of step k - 1 (RCCL, on the communicator's own stream) runs
+    # while the library's stream matches step k.  Every gather is finished before the closing barrier.
     results = [None, None]
+    gathers = [None, None]
     gathered = None
     res = None
+    gather_mode = args.gather if world > 1 else "none"
+    comm = None
+    if world > 1 and gather_mode == "library":
+        try:
+            comm = shard.library_comm(ctx, rank, world)
+        except capi.SfmError as e:  # an error, not a hang: the torch.distributed stand-by takes over on every rank
+            print(f"[rank {rank}] library communicator failed ({e}); gathering with torch.distributed", file=sys.stderr)
+            comm = None
+        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None
+            gather_mode = "torch (library communicator failed)"
 
     def launch(k):
+        if gathers[k & 1] is not None:
+            gathers[k & 1].wait()  # the gather that read this result object two steps ago
         results[k & 1] = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=results[k & 1],
                                       ratio=args.ratio)
         return results[k & 1]
 
-    def gather(r):
+    def gather(r, k):
         nonlocal gathered
+        if comm is not None:
+            gathers[k & 1] = gathered = shard.library_gather(comm, r, total_pairs, gathered=gathers[k & 1])
+            return
         total = r.total()  # cached when its step finished
         optr, pptr = r.device_ptrs()
         dev = torch.device(f"cuda:{local_rank}")
@@ -129,16 +174,19 @@ def main():
         for k in range(n_steps):
             res = launch(k)
             if world > 1 and prev is not None:
-                gather(prev)
+                gather(prev, k - 1)
             ctx.synchronize()
-            if world > 1:
+            if world > 1 and comm is None:
                 torch.cuda.synchronize()  # the gather reads prev's buffers, which step k + 1 overwrites
                 res.total()               # cached: gather() must not wait on the library's stream later
             a, b = ctx.last_kernel_ms(0)
             ms, nl = ms + a, nl + b
             prev = res
         if world > 1 and prev is not None:
-            gather(prev)
+            gather(prev, n_steps - 1)
+            for g in gathers:
+                if g is not None:
+                    g.wait()
             torch.cuda.synchronize()
         return ms, nl
 
@@ -155,6 +203,9 @@ def main():
 
     total_matches = res.total()
     cand, ovf = res.stats()
+    gathered_total = None
+    if rank == 0 and world > 1 and gathered is not None:
+        gathered_total = int(gathered.total()) if comm is not None else int(gathered[2].shape[0])
     value = total_pairs * args.steps / elapsed
     flops_per_pair = 2.0 * args.features * args.features * 128
     achieved_tflops = flops_per_pair * len(my_pairs) * args.steps / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
@@ -168,7 +219,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": bound_dtype,
         "dtype_note": ("int8-in/int32-acc" if args.bound == "int8" else "fp16-in/fp32-acc") +
@@ -182,6 +233,7 @@ def main():
             "images": n_images, "features_per_image": args.features, "dim": 128,
             "pairs_total": total_pairs, "pairs_per_gpu": pairs_per_gpu, "parallelism": f"pair-list dp{world}",
             "matches_rank0": int(total_matches), "candidates_rank0": int(cand), "overflow_rank0": int(ovf),
+            "gather": gather_mode, "matches_gathered_on_rank0": gathered_total,
             "setup_s": round(gen_s, 2),
         },
         "roofline": {
@@ -190,7 +242,10 @@ def main():
             "unit_note": "algorithmic 2*N*M*D operations per pair; with the int8 bound they are integer multiply-adds",
             "frac": round(achieved_tflops / bound_peak, 4),
             "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1), args.bound),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r1_pmc_traffic*.json)",
+            "traffic_unit": "HBM bytes per launch",
+            "traffic_source": "static, not measured in this run: bytes per pair from the committed rocprofv3 PMC passes "
+                              "(profiles/r1_pmc_traffic*.json: separate FETCH_SIZE / WRITE_SIZE runs of this script) "
+                              "times this run's pairs per launch",
             "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4), "launches": kernel_launches,
             "flops_per_pair": flops_per_pair,
         },
@@ -205,6 +260,9 @@ def main():
         out["pipeline"] = bench_pipeline(ctx, args)
     if not args.no_extensions and world == 1:
         out["extensions"] = bench_extensions(ctx, args)
+    if not args.no_regimes and world == 1:
+        out["regimes"] = bench_regimes(ctx, args, imgset, pair_list, flops_per_pair)
+        ctx.set_option("sim_variant", sim_variant)
 
     # ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -212,6 +270,11 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        for g in gathers:
+            if g is not None:
+                g.close()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -227,6 +290,70 @@ def measured_traffic(pairs_per_launch, bound="int8"):
     with open(path) as f:
         t = json.load(f)
     return round(t["hbm_bytes_per_pair"] * pairs_per_launch)
+
+
+def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
+    """The matcher outside the headline's best case.  The headline's descriptors let the int8 bound admit
+    nothing but true matches; these rows show what the same entry point costs when it does not:
+    the fp16 bound on the same data, the reference's default threshold (match.hpp:59: 0.5, where most cells
+    pass and the row-best / column-best filter decides), Gaussian float descriptors, and a distribution whose
+    unrelated descriptors sit at cosine 0.93, inside the int8 margin of a 0.95 threshold (every pair is redone
+    with the fp16 bound).  `frac` prices the strict bound kernel alone against its MFMA peak; `end_to_end_frac`
+    prices the whole call (all passes) against the peak of the bound the row starts with."""
+    from sfm_amd import synth
+    n = args.features
+
+    def row(label, s, pl, thr, variant, note):
+        sv, dtype, peak = BOUNDS[variant]
+        ctx.set_option("sim_variant", sv)
+        res = s.match(pl, threshold=thr, max_dist_sq=1e8)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        res = s.match(pl, threshold=thr, max_dist_sq=1e8, result=res)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        ms, launches = ctx.last_kernel_ms(0)
+        cand, cells, filtered, redone = res.stats_ex()
+        out = {"workload": label, "threshold": thr, "bound": variant, "pairs": len(pl), "pairs_per_s": round(len(pl) / dt, 1),
+               "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
+               # (a strict pass whose lists flood stops early and hands the pair on: its time prices nothing then)
+               "frac": round(flops_per_pair * len(pl) / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 and not (filtered or redone or cells) else None,
+               "end_to_end_frac": round(flops_per_pair * len(pl) / dt / 1e12 / peak, 4),
+               "matches_per_pair": round(res.total() / len(pl), 1), "candidates_per_pair": round(cand / len(pl), 1),
+               "pairs_scored_cell_by_cell": cells, "pairs_through_filtered_passes": filtered,
+               "pairs_redone_with_fp16_bound": redone, "note": note}
+        res.close()
+        return out
+
+    rows = []
+    head = np.ascontiguousarray(pair_list[:min(len(pair_list), 4096)])
+    rows.append(row("the headline's images", imgset, head, args.threshold, "fp16",
+                    "fp16 bound instead of int8: half the MFMA rate, a margin of 1.5e-3 instead of 2-4e-2"))
+    loose = np.ascontiguousarray(pair_list[:min(len(pair_list), 256)])
+    rows.append(row("the headline's images", imgset, loose, 0.5, "int8",
+                    "the reference's default threshold: nearly every cell passes, lists overflow, both filtered sweeps run"))
+    n_img = 40
+    pl = synth.exhaustive_pairs(n_img)
+    d, p, c = synth.image_set(n_img, n, seed=2027, kind="gauss")
+    s = ctx.imageset(c, d, p)
+    rows.append(row(f"{n_img} images x {n} Gaussian float descriptors (sigma 1; shared features re-detected with noise 0.05)",
+                    s, pl, args.threshold, "int8", "general floats: exact pass reads the fp32 table"))
+    rows.append(row(f"{n_img} images x {n} Gaussian float descriptors", s, np.ascontiguousarray(pl[:128]), 0.5, "int8",
+                    "unrelated Gaussian descriptors have cosine ~ N(0, 1/128): 0.5 is still selective"))
+    s.close()
+    rng = np.random.default_rng(7)
+    base = synth.sift_like(rng, 1)[0]
+    hard = np.clip(base[None, :] * 0.9 + synth.sift_like(rng, n_img * n) * 0.42, 0, 255).astype(np.float32)
+    shared = int(0.3 * n)
+    for im in range(1, n_img):  # 30 % of every image re-detects image 0's features
+        hard[im * n:im * n + shared] = hard[:shared]
+    pts = rng.uniform(0, 4000, (n_img * n, 2))
+    s = ctx.imageset(np.full(n_img, n, np.int32), hard, pts)
+    rows.append(row(f"{n_img} images x {n} SIFT-like descriptors with a common part: unrelated cosines ~0.93", s,
+                    np.ascontiguousarray(pl[:256]), args.threshold, "int8",
+                    "the int8 margin admits the unrelated cells, lists flood, the fp16 bound redoes every pair"))
+    s.close()
+    return rows
 
 
 def bench_extensions(ctx, args):
@@ -311,66 +438,138 @@ def bench_pipeline(ctx, args):
     return out
 
 
+def device_sample_tables(torch, dev, pairs, hyps, n_corr, seed):
+    """[pairs * hyps, 8] int32 on the device: rows of 8 distinct indices of range(n_corr), uniform (rows that
+    repeat an index are redrawn), every pair with rows of its own."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    t = torch.randint(0, n_corr, (pairs * hyps, 8), generator=gen, device=dev, dtype=torch.int32)
+    while True:
+        srt = torch.sort(t, dim=1).values
+        bad = (srt[:, 1:] == srt[:, :-1]).any(dim=1)
+        nbad = int(bad.sum().item())
+        if nbad == 0:
+            return t.contiguous()
+        t[bad] = torch.randint(0, n_corr, (nbad, 8), generator=gen, device=dev, dtype=torch.int32)
+
+
+def ransac_inputs(torch, dev, pairs, distinct, n_corr, hyps, ratio, seed):
+    """Correspondences of `pairs` image pairs on the device: `distinct` sets generated on the host (synth.two_view)
+    and repeated (separate copies in HBM), and a sample table per pair drawn on the device."""
+    from sfm_amd import synth
+    distinct = max(1, min(distinct, pairs))
+    xs, ys = [], []
+    for k in range(distinct):
+        tv = synth.two_view(n_corr, inlier_ratio=ratio, seed=[seed, k])
+        xs.append(tv["x"])
+        ys.append(tv["y"])
+    reps = (pairs + distinct - 1) // distinct
+    xd = torch.from_numpy(np.stack(xs)).to(dev).repeat(reps, 1, 1)[:pairs].reshape(-1, 2).contiguous()
+    yd = torch.from_numpy(np.stack(ys)).to(dev).repeat(reps, 1, 1)[:pairs].reshape(-1, 2).contiguous()
+    sd = device_sample_tables(torch, dev, pairs, hyps, n_corr, 1000 + seed)
+    torch.cuda.synchronize()
+    return xd, yd, sd
+
+
+def ransac_valu_profile():
+    """Vector-ALU instructions the scoring kernel executes per wave and four correspondences on the stress
+    shape, from the committed counter pass (static; None if the file is absent)."""
+    for name in ("r2_pmc_sq_ransac.json", "r1_final4_pmc_sq_ransac.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                t = json.load(f)
+            for k, v in t.items():
+                if isinstance(v, dict) and "ransac_score_kernel<0, false, true>" in k:
+                    return v.get("valu_instructions_per_wave_per_four_correspondences"), "profiles/" + name
+    return None, None
+
+
 def bench_ransac(ctx, args, rank, world, dist, local_rank):
-    """hypotheses scored/s on ransac_pairs pairs/GPU x ransac_corr correspondences (15 % inliers)
-    x ransac_hyps hypotheses, inputs resident on the device."""
+    """hypotheses scored/s on one batch of ransac_pairs pairs/GPU x ransac_corr correspondences (15 % inliers)
+    x ransac_hyps hypotheses, inputs resident on the device; at N = 1 also rows at inlier ratios where RANSAC
+    finds its model, with the pre-test on and off."""
     import torch
     from sfm_amd import synth
     P, n, H = args.ransac_pairs, args.ransac_corr, args.ransac_hyps
-    xs, ys, Ss = [], [], []
-    for k in range(P):
-        tv = synth.two_view(n, inlier_ratio=0.15, seed=[rank, k])
-        xs.append(tv["x"])
-        ys.append(tv["y"])
-        Ss.append(synth.sample_table(n, H, seed=[7, rank, k]))
     dev = torch.device(f"cuda:{local_rank}")
-    xd = torch.from_numpy(np.concatenate(xs)).to(dev)
-    yd = torch.from_numpy(np.concatenate(ys)).to(dev)
-    sd = torch.from_numpy(np.concatenate(Ss)).to(dev)
-    torch.cuda.synchronize()
-    off = np.arange(P + 1, dtype=np.int64) * n
     K = synth.default_K()
-    batch = None
 
-    def step():
-        nonlocal batch
-        batch = ctx.ransac_batch(off, None, None, K, None, H, max_sq_err=1.0, success_prob=0.999, adaptive=True,
-                                 batch=batch, device_ptrs=(xd.data_ptr(), yd.data_ptr(), sd.data_ptr()))
-        ctx.synchronize()
+    def measure(pairs, distinct, ratio, adaptive, filt, steps, seed):
+        xd, yd, sd = ransac_inputs(torch, dev, pairs, distinct, n, H, ratio, seed)
+        off = np.arange(pairs + 1, dtype=np.int64) * n
+        ctx.set_option("ransac_filter", filt)
+        batch = None
 
-    step()
-    if dist is not None:
-        dist.barrier()
-    steps = max(1, args.steps)
-    kms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
+        def step():
+            nonlocal batch
+            batch = ctx.ransac_batch(off, None, None, K, None, H, max_sq_err=1.0, success_prob=0.999, adaptive=adaptive,
+                                     batch=batch, device_ptrs=(xd.data_ptr(), yd.data_ptr(), sd.data_ptr()))
+            ctx.synchronize()
+
         step()
-        kms += ctx.last_kernel_ms(1)[0]
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        if dist is not None:
+            dist.barrier()
+        kms, launches = 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            a, b = ctx.last_kernel_ms(1)
+            kms, launches = kms + a, launches + b
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        best = batch.best()
+        batch.close()
+        ctx.set_option("ransac_filter", 1)
+        del xd, yd, sd
+        return el, kms, launches, best
+
+    steps = max(1, args.steps)
+    el, kms, launches, best = measure(P, args.ransac_distinct, 0.15, True, 1, steps, rank)
     hyps = P * H * steps * world
     pairs_s = P * steps * world / el
-    evals_s = P * H * n * steps / (kms * 1e-3) if kms > 0 else 0.0
-    best = batch.best()
-    return {
+    per4, src = ransac_valu_profile()
+    valu = None
+    if per4 and kms > 0:
+        insts = (P * H / 64.0) * (n / 4.0) * per4 * steps  # wave-instructions of this rank's timed launches
+        rate = insts / (kms * 1e-3) / 1e9
+        valu = {"bound": "valu issue", "achieved": round(rate, 1), "peak": PEAK_VALU_GINST, "unit": "G wave-instructions/s",
+                "frac": round(rate / PEAK_VALU_GINST, 4), "valu_instructions_per_wave_per_four_correspondences": per4,
+                "source": f"static, not measured in this run: SQ_INSTS_VALU of the scoring kernel from {src} "
+                          "(rocprofv3 --pmc pass of this script on the stress shape) scaled to this run's waves; peak = 1024 SIMDs x "
+                          "2.4 GHz / 4 cycles per wave64 instruction"}
+    out = {
         "metric": "RANSAC hyps scored/sec", "value": round(hyps / el, 1), "unit": "hyps/s",
-        "pairs_per_s": round(pairs_s, 2), "pairs_per_gpu": P, "correspondences": n, "hypotheses": H,
-        "inlier_ratio": 0.15, "dtype": "f64",
+        "what_it_measures": "15 % inliers, 4096 eight-point samples: no all-inlier sample exists, so every hypothesis is a "
+                            "wrong model and the rate is that of rejecting them (each still scored against all 20 000 "
+                            "correspondences: the pre-test proves > 99.9 % of the cells outliers, the rest are evaluated exactly)",
+        "pairs_per_s": round(pairs_s, 2), "pairs_per_gpu": P, "pairs_per_batch": P, "distinct_correspondence_sets": min(args.ransac_distinct, P),
+        "correspondences": n, "hypotheses": H, "inlier_ratio": 0.15, "dtype": "f64",
         "hbm_GBps_algorithmic": round(pairs_s * RANSAC_BYTES_PER_PAIR / 1e9, 3),
-        "score_kernel_ms_per_step": round(kms / steps, 3),
-        "score_kernel_algorithmic_fp64_TFLOPs": round(evals_s * RANSAC_FLOPS_PER_EVAL / 1e12, 3),
-        "fp64_vector_peak_TFLOPs": PEAK_F64_VEC_TFLOPS,
-        "flops_note": "algorithmic = every (hypothesis, correspondence) evaluation at 92 fp64 flops; the kernel proves "
-                      "most of them outliers with a packed-fp32 epipolar-distance test and evaluates only the rest, "
-                      "so this figure can exceed the fp64 vector peak; results are bit-identical to evaluating all",
+        "hbm_note": "compulsory bytes per pair (1.08 MB) x pairs/s: < 1 % of HBM bandwidth, the stage is bound by vector-ALU issue",
+        "score_kernel_ms_per_step": round(kms / steps, 3), "score_kernel_launches_per_step": launches // steps,
+        "roofline": valu,
         "mean_best_inliers": float(np.mean(best["count"])),
     }
+    if world == 1 and not args.no_regimes:
+        rows = []
+        for ratio in (0.5, 0.8):
+            for filt in (1, 0):
+                el, kms, launches, best = measure(256, 64, ratio, False, filt, 1, 50 + int(ratio * 10))
+                el2, kms2, _, best2 = measure(256, 64, ratio, True, filt, 1, 50 + int(ratio * 10))
+                rows.append({"inlier_ratio": ratio, "pre_test": bool(filt), "pairs": 256,
+                             "all_rows_scored": {"hyps_per_s": round(256 * H / el, 1), "score_kernel_ms": round(kms, 3),
+                                                 "mean_best_inliers": float(np.mean(best["count"]))},
+                             "adaptive_stop": {"pairs_per_s": round(256 / el2, 1), "score_kernel_ms": round(kms2, 3),
+                                               "mean_iterations": float(np.mean(best2["iterations"])),
+                                               "mean_best_inliers": float(np.mean(best2["count"]))}})
+        out["where_a_model_is_found"] = rows
+    return out
 
 
 def cpu_baseline(args, desc, pts, ransac_out):
@@ -396,6 +595,7 @@ def cpu_baseline(args, desc, pts, ransac_out):
     if ransac_out is not None:
         from sfm_amd import synth
         nc, Hc, Pc = args.ransac_corr, args.ransac_hyps, 8
+        oracle.emulate_shuffle(True)  # the reference shuffles all indices once per iteration (RANSAC.cpp:201)
         t0 = time.perf_counter()
         done = 0
         for k in range(Pc):
@@ -407,8 +607,12 @@ def cpu_baseline(args, desc, pts, ransac_out):
             if time.perf_counter() - t0 > 15.0:
                 break
         el = time.perf_counter() - t0
-        out["ransac"] = {"value": round(done * Hc / el, 2), "unit": "hyps/s", "cores": threads,
-                         "sample": f"{done} pairs x {nc} correspondences x {Hc} hypotheses (input generation included in the time: <5 %)"}
+        oracle.emulate_shuffle(False)
+        out["ransac"] = {"value": round(done * Hc / el, 2), "unit": "hyps/s", "cores": threads, "kind": "port",
+                         "sample": f"{done} pairs x {nc} correspondences x {Hc} hypotheses; per hypothesis the full shuffle of "
+                                   f"the {nc} indices (RANSAC.cpp:201), the fit, the triangulation of every correspondence by "
+                                   "column-pivoted QR and the loss; OpenMP over hypotheses in place of tbb::parallel_for; "
+                                   "input generation included in the time (<5 %)"}
     return out
 
 

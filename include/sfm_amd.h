@@ -377,8 +377,12 @@ int sfm_comm_create_local(int n, sfm_ctx *const *ctxs, sfm_comm **comms_out);
 int sfm_comm_rank(const sfm_comm *comm, int *rank_out, int *world_out);
 void sfm_comm_destroy(sfm_comm *comm);
 /* Gather (collective over the communicator's ranks): local = this rank's match
- * result over the pairs sfm_shard_indices gives it, in that order.  Asynchronous
- * on the context's stream apart from one synchronisation between its two steps.
+ * result over the pairs sfm_shard_indices gives it, in that order.  It runs on a
+ * stream of the communicator's own and waits only for the batch call that
+ * produced `local`, so the next batch (into another result object) may be started
+ * before the previous one is gathered; the call blocks the host once, between
+ * its two steps, until the counts have arrived.  sfm_gathered_wait blocks until
+ * the lists are in place (root) and `local` may be overwritten (every rank).
  * *gathered_inout is reused across calls (pass a pointer to NULL first). */
 int sfm_match_gather(sfm_comm *comm, sfm_match_result *local, int64_t n_pairs_total, int root,
                      sfm_gathered **gathered_inout);
@@ -397,6 +401,7 @@ int sfm_match_batch_multi(int n, sfm_comm *const *comms, const sfm_imageset *con
  * the start and length of its list in the rank-major buffer (every rank); the
  * lists themselves, pairs_out[2 * total] (root only; synchronises); device views
  * (pairs: root only, else NULL; counts[world][max_owned]). */
+int sfm_gathered_wait(sfm_gathered *g);
 int sfm_gathered_total(sfm_gathered *g, int64_t *total_out, int64_t *per_rank_totals_out);
 int sfm_gathered_layout(sfm_gathered *g, int64_t *starts_out, int32_t *counts_out);
 int sfm_gathered_pairs(sfm_gathered *g, int32_t *pairs_out);

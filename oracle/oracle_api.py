@@ -202,6 +202,13 @@ def score_cells(x, y, K, pose12, method=0):
     return lam, err
 
 
+def emulate_shuffle(on: bool) -> None:
+    """Timed CPU baseline only: ransac() also pays for the reference's per-iteration std::shuffle of all
+    correspondence indices (RANSAC.cpp:201).  Results are unchanged."""
+    lib().sfm_oracle_emulate_shuffle.argtypes = [C.c_int]
+    lib().sfm_oracle_emulate_shuffle(int(bool(on)))
+
+
 def adaptive_max_iter(n_inliers, n_total, min_n, success_prob) -> int:
     return int(lib().sfm_oracle_adaptive_max_iter(n_inliers, n_total, min_n, success_prob))
 

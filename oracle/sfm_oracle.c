@@ -873,6 +873,12 @@ void sfm_oracle_score_cells(const double *x, const double *y, int n, const doubl
     }
 }
 
+/* Timing aid of the CPU baseline: 1 = sfm_oracle_ransac also performs the per-iteration shuffle of all
+ * correspondence indices that the reference's loop does (RANSAC.cpp:201); results do not change. */
+static int g_emulate_shuffle = 0;
+static volatile int g_shuffle_sink = 0;
+void sfm_oracle_emulate_shuffle(int on) { g_emulate_shuffle = on; }
+
 /* RANSAC.cpp:14-32 */
 static int safe_cast_to_int(double value)
 {
@@ -959,11 +965,39 @@ int sfm_oracle_ransac(const double *x, const double *y, int n, const double *K, 
 
     int *counts = (int *)malloc((size_t)(H > 0 ? H : 1) * sizeof(int));
     double *toterr = (double *)malloc((size_t)(H > 0 ? H : 1) * sizeof(double));
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int h = 0; h < H; h++) {
-        double R[3][3], T[3];
-        score_hypothesis(x, y, n, K, samples + (size_t)h * minN, minN, maxSquaredError, loss_kind,
-                         &counts[h], &toterr[h], R, T);
+#pragma omp parallel
+    {
+        /* RANSAC.cpp:170-172: every worker owns a random engine and an index vector; :201 shuffles the whole
+         * vector once per iteration and keeps its first minN entries.  The rows come from the caller's table
+         * here, so the shuffle changes no result; the timed CPU baseline switches it on to pay its cost. */
+        int *indices = NULL;
+        uint64_t state = 0x9E3779B97F4A7C15ull;
+        if (g_emulate_shuffle) {
+#ifdef _OPENMP
+            state += (uint64_t)omp_get_thread_num();
+#endif
+            indices = (int *)malloc((size_t)n * sizeof(int));
+            if (indices)
+                for (int i = 0; i < n; i++)
+                    indices[i] = i;
+        }
+#pragma omp for schedule(dynamic, 4)
+        for (int h = 0; h < H; h++) {
+            if (indices) {
+                for (int i = n - 1; i > 0; i--) { /* Fisher-Yates, as std::shuffle */
+                    state = state * 6364136223846793005ull + 1442695040888963407ull;
+                    const int j = (int)(((state >> 33) * (uint64_t)(i + 1)) >> 31);
+                    const int t = indices[i];
+                    indices[i] = indices[j];
+                    indices[j] = t;
+                }
+                g_shuffle_sink += indices[0];
+            }
+            double R[3][3], T[3];
+            score_hypothesis(x, y, n, K, samples + (size_t)h * minN, minN, maxSquaredError, loss_kind,
+                             &counts[h], &toterr[h], R, T);
+        }
+        free(indices);
     }
 
     int maxIter = H;

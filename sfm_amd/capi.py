@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "sfm_match_batch_ratio", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
     "sfm_shard_count", "sfm_shard_indices", "sfm_shard_layout", "sfm_comm_unique_id", "sfm_comm_create",
     "sfm_comm_create_local", "sfm_comm_rank", "sfm_comm_destroy", "sfm_match_gather", "sfm_match_gather_local",
-    "sfm_match_batch_multi", "sfm_gathered_total", "sfm_gathered_layout", "sfm_gathered_pairs", "sfm_gathered_device",
+    "sfm_match_batch_multi", "sfm_gathered_wait", "sfm_gathered_total", "sfm_gathered_layout", "sfm_gathered_pairs", "sfm_gathered_device",
     "sfm_gathered_destroy",
 ]
 
@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
         L.sfm_match_gather.argtypes = [vp, vp, i64, i32, P(vp)]
         L.sfm_match_gather_local.argtypes = [i32, P(vp), P(vp), i64, i32, P(vp)]
         L.sfm_match_batch_multi.argtypes = [i32, P(vp), P(vp), vp, i64, i32, f32, f32, i32, P(vp), P(vp)]
+        L.sfm_gathered_wait.argtypes = [vp]
         L.sfm_gathered_total.argtypes = [vp, P(i64), vp]
         L.sfm_gathered_layout.argtypes = [vp, vp, vp]
         L.sfm_gathered_pairs.argtypes = [vp, vp]
@@ -232,6 +233,11 @@ class Gathered:
         self._h = C.c_void_p()
         self.n_total = 0
         self.root = 0
+
+    def wait(self):
+        """Blocks until the lists are in place (root) and the local result may be overwritten."""
+        if self._h:
+            self.ctx.check(lib().sfm_gathered_wait(self._h))
 
     def total(self) -> int:
         t = C.c_int64(0)

@@ -10,6 +10,8 @@
 //      posts all ncclRecv's in one group, each straight into its place in one rank-major buffer.  On an
 //      8-GPU MI355X node every peer has its own xGMI link to the root, so the transfers run side by side
 //      (no ring).
+// The gather runs on a stream that the communicator owns and waits only for the batch call whose result it
+// moves: sfm_gathered_wait (or any accessor of the lists) completes it.
 // Two ways to drive it: one process per GPU (sfm_comm_create from a broadcast id; sfm_match_gather), or
 // one process that owns several devices (sfm_comm_create_local; sfm_match_gather_local /
 // sfm_match_batch_multi), where the calls of all ranks are issued inside one RCCL group.
@@ -20,11 +22,25 @@
 
 #define SHARD_BLOCK 64 // consecutive pairs dealt to one rank (they share an image in an exhaustive list)
 
+// The gather runs on a stream of the communicator's own: it waits for the event that marks the end of the
+// batch call whose lists it moves and for nothing enqueued on the context's stream after that, so a caller
+// can start the next batch (into another result object) before it gathers the previous one.
 struct sfm_comm {
     sfm_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr; // for results that carry no event of their own
 };
+
+static int comm_streams(sfm_comm *c)
+{
+    sfm_ctx *ctx = c->ctx;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SFM_HIP(ctx, hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    return SFM_OK;
+}
 
 struct sfm_gathered {
     sfm_comm *comm = nullptr;
@@ -117,6 +133,11 @@ extern "C" int sfm_comm_create(sfm_ctx *ctx, int rank, int world, const void *id
         delete c;
         SFM_FAIL(ctx, SFM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r));
     }
+    const int rc = comm_streams(c);
+    if (rc != SFM_OK) {
+        sfm_comm_destroy(c);
+        return rc;
+    }
     *comm_out = c;
     return SFM_OK;
 }
@@ -149,6 +170,10 @@ extern "C" int sfm_comm_create_local(int n, sfm_ctx *const *ctxs, sfm_comm **com
         c->world = n;
         comms_out[i] = c;
     }
+    for (int i = 0; i < n; i++) {
+        const int rc = comm_streams(comms_out[i]);
+        if (rc != SFM_OK) return rc;
+    }
     return SFM_OK;
 }
 
@@ -157,7 +182,10 @@ extern "C" void sfm_comm_destroy(sfm_comm *c)
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;
 }
 
@@ -208,11 +236,17 @@ static int gather_enqueue_counts(sfm_comm *c, sfm_match_result *local, int64_t n
     SFM_HIP(ctx, g->totalsMine.reserve(sizeof(int64_t)));
     SFM_HIP(ctx, g->totalsAll.reserve((size_t)c->world * sizeof(int64_t)));
     g->totals.assign(c->world, 0);
-    hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, ctx->stream,
+    if (local->done) {
+        SFM_HIP(ctx, hipStreamWaitEvent(c->stream, local->done, 0));
+    } else { // whatever the context's stream holds by now
+        SFM_HIP(ctx, hipEventRecord(c->ev, ctx->stream));
+        SFM_HIP(ctx, hipStreamWaitEvent(c->stream, c->ev, 0));
+    }
+    hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, c->stream,
                        local->offsets.as<int64_t>(), nOwned, (int64_t)padded, g->countsMine.as<int32_t>(), g->totalsMine.as<int64_t>());
     SFM_HIP(ctx, hipGetLastError());
-    SFM_NCCL(ctx, ncclAllGather(g->countsMine.p, g->countsAll.p, padded, ncclInt32, c->comm, ctx->stream));
-    SFM_NCCL(ctx, ncclAllGather(g->totalsMine.p, g->totalsAll.p, 1, ncclInt64, c->comm, ctx->stream));
+    SFM_NCCL(ctx, ncclAllGather(g->countsMine.p, g->countsAll.p, padded, ncclInt32, c->comm, c->stream));
+    SFM_NCCL(ctx, ncclAllGather(g->totalsMine.p, g->totalsAll.p, 1, ncclInt64, c->comm, c->stream));
     return SFM_OK;
 }
 
@@ -222,8 +256,8 @@ static int gather_fetch_totals(sfm_gathered *g)
     sfm_comm *c = g->comm;
     sfm_ctx *ctx = c->ctx;
     SFM_HIP(ctx, hipSetDevice(ctx->device));
-    SFM_HIP(ctx, hipMemcpyAsync(g->totals.data(), g->totalsAll.p, (size_t)c->world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFM_HIP(ctx, hipMemcpyAsync(g->totals.data(), g->totalsAll.p, (size_t)c->world * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(c->stream));
     g->total = 0;
     for (int r = 0; r < c->world; r++) {
         if (g->totals[r] < 0) SFM_FAIL(ctx, SFM_ERR_HIP, "gather: rank %d reports a negative total", r);
@@ -245,14 +279,14 @@ static int gather_enqueue_payload(sfm_gathered *g, sfm_match_result *local)
             int2 *dst = g->payload.as<int2>() + base;
             if (g->totals[r] > 0) {
                 if (r == c->rank)
-                    SFM_HIP(ctx, hipMemcpyAsync(dst, local->pairs.p, (size_t)g->totals[r] * sizeof(int2), hipMemcpyDeviceToDevice, ctx->stream));
+                    SFM_HIP(ctx, hipMemcpyAsync(dst, local->pairs.p, (size_t)g->totals[r] * sizeof(int2), hipMemcpyDeviceToDevice, c->stream));
                 else
-                    SFM_NCCL(ctx, ncclRecv(dst, (size_t)g->totals[r] * 2, ncclInt32, r, c->comm, ctx->stream));
+                    SFM_NCCL(ctx, ncclRecv(dst, (size_t)g->totals[r] * 2, ncclInt32, r, c->comm, c->stream));
             }
             base += g->totals[r];
         }
     } else if (g->totals[c->rank] > 0) {
-        SFM_NCCL(ctx, ncclSend(local->pairs.p, (size_t)g->totals[c->rank] * 2, ncclInt32, g->root, c->comm, ctx->stream));
+        SFM_NCCL(ctx, ncclSend(local->pairs.p, (size_t)g->totals[c->rank] * 2, ncclInt32, g->root, c->comm, c->stream));
     }
     return SFM_OK;
 }
@@ -316,8 +350,8 @@ static int gathered_fetch_counts(sfm_gathered *g)
     const size_t padded = (size_t)std::max<int64_t>(g->max_owned, 1);
     g->countsHost.resize(padded * g->comm->world);
     SFM_HIP(ctx, hipSetDevice(ctx->device));
-    SFM_HIP(ctx, hipMemcpyAsync(g->countsHost.data(), g->countsAll.p, g->countsHost.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFM_HIP(ctx, hipMemcpyAsync(g->countsHost.data(), g->countsAll.p, g->countsHost.size() * sizeof(int32_t), hipMemcpyDeviceToHost, g->comm->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(g->comm->stream));
     g->countsFetched = true;
     return SFM_OK;
 }
@@ -341,9 +375,9 @@ extern "C" int sfm_gathered_pairs(sfm_gathered *g, int32_t *pairs_out)
     SFM_HIP(ctx, hipSetDevice(ctx->device));
     if (g->total > 0) {
         if (!pairs_out) return SFM_ERR_INVALID_ARG;
-        SFM_HIP(ctx, hipMemcpyAsync(pairs_out, g->payload.p, (size_t)g->total * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipMemcpyAsync(pairs_out, g->payload.p, (size_t)g->total * sizeof(int2), hipMemcpyDeviceToHost, g->comm->stream));
     }
-    SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFM_HIP(ctx, hipStreamSynchronize(g->comm->stream));
     return SFM_OK;
 }
 
@@ -355,12 +389,23 @@ extern "C" int sfm_gathered_device(sfm_gathered *g, const int32_t **pairs_device
     return SFM_OK;
 }
 
+// Blocks until the gather has finished on this rank: its lists are in place on the root, and the local
+// result it read may be overwritten.
+extern "C" int sfm_gathered_wait(sfm_gathered *g)
+{
+    if (!g || !g->comm) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = g->comm->ctx;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipStreamSynchronize(g->comm->stream));
+    return SFM_OK;
+}
+
 extern "C" void sfm_gathered_destroy(sfm_gathered *g)
 {
     if (!g) return;
     if (g->comm) {
         (void)hipSetDevice(g->comm->ctx->device);
-        (void)hipStreamSynchronize(g->comm->ctx->stream);
+        (void)hipStreamSynchronize(g->comm->stream);
     }
     DevBuf *bufs[] = {&g->countsMine, &g->countsAll, &g->totalsMine, &g->totalsAll, &g->payload};
     for (DevBuf *d : bufs) d->release();

@@ -1158,6 +1158,8 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
+    (void)hipStreamSynchronize(r->ctx->stream2); // a call that failed half-way may have left work of this result there
+    if (r->done) (void)hipEventDestroy(r->done);
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
                       &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2, &r->kill};
     for (DevBuf *b : bufs) b->release();
@@ -1192,8 +1194,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     } else if (res->ctx != ctx) {
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: result belongs to another context");
     } else {
-        // the staging buffers of a reused result may still be the source of copies in flight
+        // the staging buffers of a reused result may still be the source of copies in flight (on the second
+        // stream too, when an earlier call failed between its fork and its join)
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     }
     res->n_pairs = n_pairs;
     res->total = -1;
@@ -1498,12 +1502,22 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     return SFM_OK;
 }
 
+// The point on the context's stream where a batch call's lists are complete (the multi-GPU gather, which
+// runs on a stream of its own, waits for it).
+static int mark_done(sfm_ctx *ctx, sfm_match_result *res)
+{
+    if (!res->done) SFM_HIP(ctx, hipEventCreateWithFlags(&res->done, hipEventDisableTiming));
+    SFM_HIP(ctx, hipEventRecord(res->done, ctx->stream));
+    return SFM_OK;
+}
+
 extern "C" int sfm_match_batch(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
                                int metric, float threshold, float max_distance_px_squared,
                                sfm_match_result **result_inout)
 {
-    return match_batch_impl(ctx, set, pair_list, n_pairs, metric, threshold, max_distance_px_squared,
-                            result_inout, false);
+    const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, metric, threshold, max_distance_px_squared,
+                                    result_inout, false);
+    return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
 }
 
 extern "C" int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
@@ -1512,8 +1526,9 @@ extern "C" int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set, cons
 {
     if (ctx && !(ratio > 0.0f && ratio <= 1.0f))
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1], was %g", (double)ratio);
-    return match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_COSINE, threshold, max_distance_px_squared,
-                            result_inout, false, ratio);
+    const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_COSINE, threshold, max_distance_px_squared,
+                                    result_inout, false, ratio);
+    return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
 }
 
 extern "C" int sfm_match_result_total(sfm_match_result *res, int64_t *total_out)

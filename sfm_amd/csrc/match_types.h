@@ -81,5 +81,6 @@ struct sfm_match_result {
     DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2, kill;
     PinBuf hostRecs, hostWork;
     int64_t total = -1;
+    hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
 };
 
