@@ -78,6 +78,7 @@ const char *sfm_version(void);
  * goes through in windows of steps; results are identical), "hamming_mfma"
  * (1 = 256-bit binary descriptors are first matched on the matrix cores as
  * sign vectors, default; 0 = popcount kernel only; results are identical),
+ * "ransac_seed" / "ransac_max_time_ms" (single-pair RANSAC: see sfm_ransac_pair),
  * "match_overlap" (1 = a batch of several chunks runs what follows a chunk's
  * bound passes on a second stream of the context while the next chunk's bound
  * passes start, default; 0 = everything on one stream; results are identical;
@@ -184,7 +185,16 @@ void sfm_match_result_destroy(sfm_match_result *res);
  * x, y: n x 2 doubles, K^-1-normalised (scene.cpp:246-247); K: 3x3
  * column-major.  samples[n_hyp][8]: the index rows to fit (the reference draws
  * them with a time-seeded shuffle, RANSAC.cpp:170,201, so any table is a legal
- * run); hypotheses are taken in row order, as one TBB worker would.
+ * run); hypotheses are taken in row order, as one TBB worker would.  samples ==
+ * NULL: the library draws the table on the device (the generator documented at
+ * sfm_corr_sample_table, pair index 0) from the context option "ransac_seed"
+ * (0, the default: seeded from the clock, as the reference).  The context option
+ * "ransac_max_time_ms" (default 0 = none) is RANSAC_OPTIONS::maxTimeMs
+ * (RANSAC.cpp:189-196): with adaptive != 0 and no per-row outputs the rows are
+ * scored in growing slices, and once the device clock passes the limit no further
+ * slice is scored.
+ * inliers_out receives up to min(n, capacity) entries of which the first
+ * *count_out are the result.
  * min_n must be 8 (RANSAC_OPTIONS::minN, solve.hpp:113); other values ->
  * SFM_ERR_UNSUPPORTED.  n < min_n -> count 0 (RANSAC.cpp:148-149).
  * adaptive != 0 applies the maxIter update of RANSAC.cpp:245-258 while
@@ -220,6 +230,15 @@ int sfm_ransac_pair_static(sfm_ctx *ctx, const double *x, const double *y, int n
  * Replaces the fit half of eightPointAlgorithmFromSubset (eightPoint.cpp:233-344). */
 int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n,
                         const int32_t *samples, int n_hyp, double *pose12_out);
+
+/* The whole of eightPointAlgorithmFromSubset (eightPoint.cpp:225-372): pose from the
+ * n_calc = 8 sample correspondences, then every one of the n_all correspondences
+ * triangulated under it (depth through float, :365).  pose16_out column-major
+ * [R|T; 0 0 0 1], points_out[n_all][3]; either may be NULL.  n_calc < 8 ->
+ * SFM_ERR_INVALID_ARG with the reference's message; n_calc > 8 -> SFM_ERR_UNSUPPORTED. */
+int sfm_eight_point_from_subset(sfm_ctx *ctx, const double *calc1, const double *calc2, int n_calc,
+                                const double *all1, const double *all2, int n_all,
+                                double *pose16_out, double *points_out);
 
 /* eightPointAlgorithm(points1, points2), eightPoint.cpp:57-223, on one point
  * set: pose16_out = column-major [R|T; 0 0 0 1], points_out[n][3] (either may be

@@ -6,7 +6,8 @@ Names and argument meaning follow the reference (namespace SfM::match / SfM::sol
   RANSAC(x, y, K, options, verbose)                 submodules/solve/solve.hpp:137
   RANSAC_OPTIONS                                    submodules/solve/solve.hpp:108-125
 The two `std::function` plug-in points are mirrored by sentinel objects: only the
-reference's own functors have kernels; anything else raises (there is no CPU fallback).
+reference's own functors have kernels; anything else raises (there is no CPU fallback in this
+package; the C++ adaptors under adaptors/ keep the reference's CPU loop for user functors).
 """
 from __future__ import annotations
 
@@ -126,9 +127,11 @@ def RANSAC(x, y, K, options: RANSAC_OPTIONS = RANSAC_OPTIONS(), verbose: bool = 
            seed: int = 0, ctx: Optional[capi.Context] = None) -> List[int]:
     """SfM::solve::RANSAC (RANSAC.cpp:146-270): indices of the largest inlier set.
 
-    samples: optional [maxIter, minN] index table; by default one is drawn from `seed`
-    (the reference seeds from the wall clock, RANSAC.cpp:170, so any table is a legal run)."""
-    from . import synth
+    One library call: the rows of the sample table are fitted and scored in growing slices, the adaptive
+    iteration cap (RANSAC.cpp:245-258) and the wall-clock cap (:189-196) are applied between slices on the
+    device, and the winner's inlier list comes back.
+    samples: optional [maxIter, minN] index table; by default the library draws one on the device from `seed`
+    (0: from the clock; the reference seeds from the wall clock, RANSAC.cpp:170, so any table is a legal run)."""
     x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
     y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
     if len(x) != len(y) or len(x) < options.minN:  # RANSAC.cpp:148-149
@@ -141,40 +144,17 @@ def RANSAC(x, y, K, options: RANSAC_OPTIONS = RANSAC_OPTIONS(), verbose: bool = 
         raise NotImplementedError("minN must be 8")
     ctx = ctx or default_context()
     start = time.monotonic()
-    if samples is None:
-        samples = synth.sample_table(len(x), options.maxIter, seed=seed)
-    samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8)[:options.maxIter]
-    # Hypotheses are scored in chunks; between chunks the adaptive cap (RANSAC.cpp:245-258) and
-    # the wall-clock cap (:189-196) are applied exactly as one in-order worker would meet them.
-    chunk = 1024
-    best_key, best_h, best_inl = (0, -math.inf), -1, np.zeros(0, np.int32)
-    max_iter, done = len(samples), 0
-    while done < max_iter:
-        if (time.monotonic() - start) * 1000.0 > options.maxTimeMs:
-            break
-        hi = min(done + chunk, max_iter)
-        r = ctx.ransac_pair(x, y, K, samples[done:hi], max_sq_err=options.maxSquaredError,
-                            success_prob=options.successProb, adaptive=False, loss=options.loss.code)
-        for h in range(hi - done):
-            if done + h >= max_iter:
-                break
-            c, e = int(r["counts"][h]), float(r["toterr"][h])
-            if c > 0 and (c > best_key[0] or (c == best_key[0] and e < -best_key[1])):
-                best_key, best_h = (c, -e), done + h
-                sp = (c / len(x)) ** options.minN
-                if sp >= 1e-6:
-                    new_max = safeCastToInt(math.ceil(math.log(1.0 - options.successProb) / math.log(1 - sp))) \
-                        if sp < 1.0 else 0
-                    if verbose:
-                        print(f"RANSAC: found better model with {c} inliers that have a total error of {e}, "
-                              f"maxIter adjusted to {min(new_max, max_iter)}.")
-                    max_iter = min(max_iter, new_max)
-        done = hi
-    if best_h >= 0:
-        r = ctx.ransac_pair(x, y, K, samples[best_h:best_h + 1], max_sq_err=options.maxSquaredError,
-                            success_prob=options.successProb, adaptive=False, loss=options.loss.code)
-        best_inl = r["inliers"]
+    if samples is not None:
+        samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8)[:max(options.maxIter, 0)]
+    ctx.set_option("ransac_seed", int(seed))
+    ctx.set_option("ransac_max_time_ms", max(int(options.maxTimeMs), 0))
+    try:
+        r = ctx.ransac_pair(x, y, K, samples if samples is not None else max(int(options.maxIter), 0),
+                            max_sq_err=options.maxSquaredError, success_prob=options.successProb, adaptive=True,
+                            loss=options.loss.code, per_row=False)
+    finally:
+        ctx.set_option("ransac_seed", 0)
+        ctx.set_option("ransac_max_time_ms", 0)
     if verbose:
-        print(f"RANSAC: finished after {min(done, max_iter)} iterations "
-              f"({int((time.monotonic() - start) * 1000)}ms).")
-    return [int(i) for i in best_inl]
+        print(f"RANSAC: finished after {r['iterations']} iterations ({int((time.monotonic() - start) * 1000)}ms).")
+    return [int(i) for i in r["inliers"]]

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
     "sfm_match_result_destroy",
-    "sfm_ransac_pair", "sfm_ransac_pair_static", "sfm_eight_point_fit", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
+    "sfm_ransac_pair", "sfm_ransac_pair_static", "sfm_eight_point_fit", "sfm_eight_point_from_subset", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
         L.sfm_ransac_pair_static.argtypes = L.sfm_ransac_pair.argtypes
     L.sfm_eight_point_fit.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     L.sfm_eight_point_algorithm.argtypes = [vp, vp, vp, i32, vp, vp]
+    if hasattr(L, "sfm_eight_point_from_subset"):
+        L.sfm_eight_point_from_subset.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp]
     L.sfm_ransac_batch_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
     L.sfm_ransac_batch_run_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, f64, f64, i32, i32, P(vp)]
     L.sfm_ransac_batch_best.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -411,8 +413,12 @@ class Context:
             return dict(inliers=np.zeros(0, np.int32), best_h=-1, pose=np.eye(4), counts=None, toterr=None,
                         iterations=0)
         Kc = np.asfortranarray(K, np.float64).reshape(-1, order="F").copy()
-        samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8 if min_n == 8 else min_n)
-        H, n = samples.shape[0], len(x)
+        if isinstance(samples, (int, np.integer)):  # a row count: the library draws the table on the device
+            H, samples = int(samples), None
+        else:
+            samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8 if min_n == 8 else min_n)
+            H = samples.shape[0]
+        n = len(x)
         inl = np.zeros(max(n, 1), np.int32)
         pose = np.eye(4).reshape(-1, order="F").copy()
         counts = np.zeros(max(H, 1), np.int32) if per_row else None
@@ -451,6 +457,18 @@ class Context:
                                          _ptr(start_c), float(max_translation), int(n_tracks), _ptr(out[0]),
                                          _ptr(out[1]), _ptr(out[2]), _ptr(out[3])))
         return _chain_result(out, S, n_tracks)
+
+    def eight_point_from_subset(self, calc1, calc2, all1, all2):
+        """eightPointAlgorithmFromSubset (eightPoint.cpp:225-372): (pose 4x4, points [n_all,3])."""
+        c1 = np.ascontiguousarray(calc1, np.float64).reshape(-1, 2)
+        c2 = np.ascontiguousarray(calc2, np.float64).reshape(-1, 2)
+        a1 = np.ascontiguousarray(all1, np.float64).reshape(-1, 2)
+        a2 = np.ascontiguousarray(all2, np.float64).reshape(-1, 2)
+        pose = np.zeros(16)
+        pts = np.zeros((max(len(a1), 1), 3))
+        self.check(lib().sfm_eight_point_from_subset(self._h, _ptr(c1), _ptr(c2), len(c1), _ptr(a1), _ptr(a2), len(a1),
+                                                     _ptr(pose), _ptr(pts)))
+        return pose.reshape(4, 4, order="F").copy(), pts[:len(a1)]
 
     def eight_point_algorithm(self, x, y):
         """eightPointAlgorithm (eightPoint.cpp:57-223): (pose 4x4, points [n,3])."""

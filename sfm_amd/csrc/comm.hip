@@ -31,6 +31,8 @@ struct sfm_comm {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipEvent_t ev = nullptr; // for results that carry no event of their own
+    int refs = 1;            // the caller's handle, and one per gathered object that uses this communicator
+    bool closed = false;     // sfm_comm_destroy has been called
 };
 
 static int comm_streams(sfm_comm *c)
@@ -123,6 +125,7 @@ extern "C" int sfm_comm_create(sfm_ctx *ctx, int rank, int world, const void *id
     SFM_HIP(ctx, hipSetDevice(ctx->device));
     sfm_comm *c = new (std::nothrow) sfm_comm();
     if (!c) SFM_FAIL(ctx, SFM_ERR_OOM, "comm: host allocation failed");
+    sfm_ctx_retain(ctx);
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
@@ -131,6 +134,7 @@ extern "C" int sfm_comm_create(sfm_ctx *ctx, int rank, int world, const void *id
     ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
     if (r != ncclSuccess) {
         delete c;
+        sfm_ctx_release(ctx);
         SFM_FAIL(ctx, SFM_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(r));
     }
     const int rc = comm_streams(c);
@@ -159,11 +163,15 @@ extern "C" int sfm_comm_create_local(int n, sfm_ctx *const *ctxs, sfm_comm **com
         sfm_comm *c = new (std::nothrow) sfm_comm();
         if (!c) {
             for (int j = 0; j < n; j++) {
-                if (j < i) delete comms_out[j];
+                if (j < i) {
+                    delete comms_out[j];
+                    sfm_ctx_release(ctxs[j]);
+                }
                 (void)ncclCommDestroy(comms[j]);
             }
             SFM_FAIL(ctxs[0], SFM_ERR_OOM, "comm: host allocation failed");
         }
+        sfm_ctx_retain(ctxs[i]);
         c->ctx = ctxs[i];
         c->comm = comms[i];
         c->rank = i;
@@ -177,16 +185,28 @@ extern "C" int sfm_comm_create_local(int n, sfm_ctx *const *ctxs, sfm_comm **com
     return SFM_OK;
 }
 
+static void comm_release(sfm_comm *c);
+
+// Gathered objects made with the communicator keep it (and its stream) alive until they are destroyed too.
 extern "C" void sfm_comm_destroy(sfm_comm *c)
 {
-    if (!c) return;
+    if (!c || c->closed) return;
+    c->closed = true;
+    comm_release(c);
+}
+
+static void comm_release(sfm_comm *c)
+{
+    if (--c->refs > 0) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->ev) (void)hipEventDestroy(c->ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    sfm_ctx *owner = c->ctx;
     delete c;
+    sfm_ctx_release(owner);
 }
 
 extern "C" int sfm_comm_rank(const sfm_comm *c, int *rank_out, int *world_out)
@@ -223,6 +243,10 @@ static int gather_enqueue_counts(sfm_comm *c, sfm_match_result *local, int64_t n
         g = new (std::nothrow) sfm_gathered();
         if (!g) SFM_FAIL(ctx, SFM_ERR_OOM, "gather: host allocation failed");
         *g_inout = g;
+    }
+    if (g->comm != c) {
+        if (g->comm) comm_release(g->comm);
+        c->refs++;
     }
     g->comm = c;
     g->n_total = n_total;
@@ -409,6 +433,7 @@ extern "C" void sfm_gathered_destroy(sfm_gathered *g)
     }
     DevBuf *bufs[] = {&g->countsMine, &g->countsAll, &g->totalsMine, &g->totalsAll, &g->payload};
     for (DevBuf *d : bufs) d->release();
+    if (g->comm) comm_release(g->comm);
     delete g;
 }
 

@@ -12,6 +12,11 @@
 #include "../../include/sfm_amd.h"
 
 struct sfm_ctx {
+    // Every object made on a context (image sets, results, batches, communicators, ...) holds a reference to
+    // it and reads its stream when it is destroyed.  sfm_ctx_destroy drops the caller's reference; the streams
+    // and events go when the last object has gone too, so handles may be destroyed in any order.
+    int refs = 1;
+    bool closed = false; // sfm_ctx_destroy has been called
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -40,13 +45,24 @@ struct sfm_ctx {
     sfm_imageset *pair_set = nullptr;       // and of the single-pair matcher
     sfm_match_result *pair_result = nullptr;
     int64_t chain_table_entries = (int64_t)1 << 26;
+    // single-pair RANSAC: seed of the sample table the library draws when the caller passes none (0 = from the
+    // clock, as the reference does, RANSAC.cpp:170), and the wall-clock cap of RANSAC_OPTIONS::maxTimeMs
+    // (RANSAC.cpp:189-196), checked on the device between slices of sample rows (0 = none)
+    uint64_t ransac_seed = 0;
+    int64_t ransac_max_time_ms = 0;
 };
+void sfm_ctx_retain(sfm_ctx *ctx);
+void sfm_ctx_release(sfm_ctx *ctx); // tears the context down when the last reference goes
 void sfm_chain_scratch_free(sfm_ctx *ctx);
 void sfm_pair_batch_free(sfm_ctx *ctx);
 void sfm_pair_match_free(sfm_ctx *ctx);
 // Per-device set-up of the RANSAC entry point that allocates nothing (address of its static workspace);
 // called by sfm_ctx_create with the device current.
 int sfm_ransac_static_setup(int device);
+// Sample tables drawn on the device (the generator documented with sfm_corr_sample_table): offsets[n_pairs + 1]
+// device, samples[n_pairs][n_hyp][8] device.
+void sfm_launch_sample_table(const int64_t *offsets_device, int n_pairs, int n_hyp, uint64_t seed, int32_t *samples_device,
+                             hipStream_t st);
 
 #define SFM_FAIL(ctx, code, ...)                                   \
     do {                                                           \

@@ -38,17 +38,14 @@ extern "C" int sfm_ctx_create(int device, sfm_ctx **ctx_out)
     return SFM_OK;
 }
 
-extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
+void sfm_ctx_retain(sfm_ctx *ctx) { ctx->refs++; }
+
+static void ctx_teardown(sfm_ctx *ctx)
 {
-    if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-    sfm_chain_scratch_free(ctx);
-    sfm_pair_batch_free(ctx);
-    sfm_pair_match_free(ctx);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    // events first: some were recorded on the streams that go next
     for (int k = 0; k < 7; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     for (int w = 0; w < 2; w++)
@@ -56,7 +53,31 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
             (void)hipEventDestroy(s.a);
             (void)hipEventDestroy(s.b);
         }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     delete ctx;
+}
+
+void sfm_ctx_release(sfm_ctx *ctx)
+{
+    if (--ctx->refs == 0) ctx_teardown(ctx);
+}
+
+// The caller is done with the context.  Objects made on it that are still alive keep its streams alive
+// (they synchronise on them when they are destroyed) and may still be read; the context goes with the last
+// of them.  A second sfm_ctx_destroy of the same handle is an error of the caller, as free() twice is.
+extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
+{
+    if (!ctx || ctx->closed) return;
+    ctx->closed = true;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    // the objects the context made for its own use (each holds a reference)
+    sfm_chain_scratch_free(ctx);
+    sfm_pair_batch_free(ctx);
+    sfm_pair_match_free(ctx);
+    sfm_ctx_release(ctx);
 }
 
 extern "C" int sfm_ctx_synchronize(sfm_ctx *ctx)
@@ -92,6 +113,11 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->ransac_split = value != 0;
     } else if (!strcmp(key, "ransac_filter")) {
         ctx->ransac_filter = value != 0;
+    } else if (!strcmp(key, "ransac_seed")) {
+        ctx->ransac_seed = (uint64_t)value;
+    } else if (!strcmp(key, "ransac_max_time_ms")) {
+        if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac_max_time_ms must be >= 0");
+        ctx->ransac_max_time_ms = value;
     } else if (!strcmp(key, "sim_variant")) {
         if (value < 0 || value >= sfm_num_sim_variants())
             SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "sim_variant must be in [0, %d)", sfm_num_sim_variants());

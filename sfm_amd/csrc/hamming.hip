@@ -191,7 +191,9 @@ extern "C" void sfm_binset_destroy(sfm_binset *s)
     s->bits.release();
     s->pts.release();
     s->signs.release();
+    sfm_ctx *owner = s->ctx;
     delete s;
+    sfm_ctx_release(owner);
 }
 
 extern "C" int sfm_binset_create(sfm_ctx *ctx, int n_images, const int32_t *counts, const uint8_t *desc,
@@ -205,6 +207,7 @@ extern "C" int sfm_binset_create(sfm_ctx *ctx, int n_images, const int32_t *coun
     SFM_HIP(ctx, hipSetDevice(ctx->device));
     sfm_binset *s = new (std::nothrow) sfm_binset();
     if (!s) SFM_FAIL(ctx, SFM_ERR_OOM, "binary set: host allocation failed");
+    sfm_ctx_retain(ctx);
     s->ctx = ctx;
     s->n_images = n_images;
     s->words = bytes_per_desc / 4;
@@ -212,14 +215,14 @@ extern "C" int sfm_binset_create(sfm_ctx *ctx, int n_images, const int32_t *coun
     s->row.resize((size_t)n_images + 1, 0);
     for (int i = 0; i < n_images; i++) {
         if (counts[i] < 0) {
-            delete s;
+            sfm_binset_destroy(s);
             SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "binary set: counts[%d] < 0", i);
         }
         s->row[(size_t)i + 1] = s->row[i] + counts[i];
     }
     s->rows = s->row[n_images];
     if (s->rows > 0 && (!desc || !pts)) {
-        delete s;
+        sfm_binset_destroy(s);
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "binary set: null descriptor or point table");
     }
     const size_t bBits = (size_t)s->rows * bytes_per_desc, bPts = (size_t)s->rows * 2 * sizeof(double);
@@ -276,6 +279,7 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
     if (!res) {
         res = new (std::nothrow) sfm_match_result();
         if (!res) SFM_FAIL(ctx, SFM_ERR_OOM, "hamming: host allocation failed");
+        sfm_ctx_retain(ctx);
         res->ctx = ctx;
         *result_inout = res;
     } else if (res->ctx != ctx) {

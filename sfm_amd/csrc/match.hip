@@ -959,7 +959,9 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
     if (s->owns_pts) s->pts.release();
     s->imageRecs.release();
     s->imageFlags.release();
+    sfm_ctx *owner = s->ctx;
     delete s;
+    sfm_ctx_release(owner);
 }
 
 extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
@@ -992,9 +994,11 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     if (n_images > 65535) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "imageset: more than 65535 images");
     SFM_HIP(ctx, hipSetDevice(ctx->device));
 
-    sfm_imageset *s = (reuse && *reuse) ? *reuse : new (std::nothrow) sfm_imageset();
+    const bool fresh = !(reuse && *reuse);
+    sfm_imageset *s = fresh ? new (std::nothrow) sfm_imageset() : *reuse;
     if (!s) SFM_FAIL(ctx, SFM_ERR_OOM, "imageset: host allocation failed");
     if (reuse) *reuse = nullptr;
+    if (fresh) sfm_ctx_retain(ctx);
     s->ctx = ctx;
     s->scale8.clear();
     s->l1max.clear();
@@ -1165,7 +1169,9 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
+    sfm_ctx *owner = r->ctx;
     delete r;
+    sfm_ctx_release(owner);
 }
 
 int sfm_num_sim_variants() { return kNumSimVariants; }
@@ -1189,6 +1195,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     if (!res) {
         res = new (std::nothrow) sfm_match_result();
         if (!res) SFM_FAIL(ctx, SFM_ERR_OOM, "match: host allocation failed");
+        sfm_ctx_retain(ctx);
         res->ctx = ctx;
         *result_inout = res;
     } else if (res->ctx != ctx) {

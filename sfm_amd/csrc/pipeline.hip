@@ -90,6 +90,14 @@ __global__ __launch_bounds__(256) void sample_table_kernel(const int64_t *__rest
     *reinterpret_cast<int4 *>(dst + 4) = make_int4(pick[4], pick[5], pick[6], pick[7]);
 }
 
+void sfm_launch_sample_table(const int64_t *offsets_device, int n_pairs, int n_hyp, uint64_t seed, int32_t *samples_device,
+                             hipStream_t st)
+{
+    if (n_pairs <= 0 || n_hyp <= 0) return;
+    hipLaunchKernelGGL(sample_table_kernel, dim3((n_hyp + 255) / 256, n_pairs), dim3(256), 0, st, offsets_device, n_hyp,
+                       (u64)seed, samples_device);
+}
+
 struct sfm_corr {
     sfm_ctx *ctx = nullptr;
     int n_pairs = 0;
@@ -108,7 +116,9 @@ extern "C" void sfm_corr_destroy(sfm_corr *c)
     c->x.release();
     c->y.release();
     c->samples.release();
+    sfm_ctx *owner = c->ctx;
     delete c;
+    sfm_ctx_release(owner);
 }
 
 extern "C" int sfm_corr_from_matches(sfm_ctx *ctx, const sfm_imageset *set, sfm_match_result *res,
@@ -123,6 +133,7 @@ extern "C" int sfm_corr_from_matches(sfm_ctx *ctx, const sfm_imageset *set, sfm_
     if (!c) {
         c = new (std::nothrow) sfm_corr();
         if (!c) SFM_FAIL(ctx, SFM_ERR_OOM, "correspondences: host allocation failed");
+        sfm_ctx_retain(ctx);
         c->ctx = ctx;
         *corr_inout = c;
     } else if (c->ctx != ctx) {
@@ -192,8 +203,7 @@ extern "C" int sfm_corr_sample_table(sfm_corr *c, int n_hyp, uint64_t seed, cons
     if (cells > 0) {
         SFM_HIP(ctx, hipMemcpyAsync(c->offsetsDev.p, c->offsets.data(), c->offsets.size() * sizeof(int64_t),
                                     hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(sample_table_kernel, dim3((n_hyp + 255) / 256, c->n_pairs), dim3(256), 0, ctx->stream,
-                           c->offsetsDev.as<int64_t>(), n_hyp, (u64)seed, c->samples.as<int32_t>());
+        sfm_launch_sample_table(c->offsetsDev.as<int64_t>(), c->n_pairs, n_hyp, seed, c->samples.as<int32_t>(), ctx->stream);
         SFM_HIP(ctx, hipGetLastError());
         if (samples_out) {
             SFM_HIP(ctx, hipMemcpyAsync(samples_out, c->samples.p, cells * sizeof(int32_t), hipMemcpyDeviceToHost,

@@ -65,6 +65,9 @@ struct RansacArgs {
     int hBegin, hEnd;
     int *active;  // [P] 1 while the pair's scan has not stopped
     int *maxIter; // [P] the scan's current iteration cap
+    // wall-clock cap (RANSAC.cpp:189-196): device clock at the start of the call, and the ticks it may run
+    const unsigned long long *t0;
+    long long maxTicks; // 0 = no cap
 };
 
 // ---------------------------------------------------------------------------------------
@@ -1068,8 +1071,10 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
         g.bestErr[p] = bestError;
         g.iterations[p] = stop;
         g.maxIter[p] = capOut;
-        // the scan goes on iff it consumed this phase without reaching its cap and rows remain
-        g.active[p] = (stop == g.hEnd && stop < capOut && g.hEnd < g.H) ? 1 : 0;
+        // the scan goes on iff it consumed this phase without reaching its cap and rows remain, and the
+        // caller's time is not up (the reference looks at the clock every 50 iterations and stops the loop)
+        const bool timeUp = g.maxTicks > 0 && (long long)(wall_clock64() - *g.t0) > g.maxTicks;
+        g.active[p] = (stop == g.hEnd && stop < capOut && g.hEnd < g.H && !timeUp) ? 1 : 0;
     }
 }
 
@@ -1407,6 +1412,51 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
     }
 }
 
+__global__ void ransac_clock_kernel(unsigned long long *t0) { *t0 = wall_clock64(); }
+
+// eightPoint.cpp:349-369 on its own: every correspondence triangulated under one pose (R row-major, then T),
+// depth through float (:365), point = depth * (x1, y1, 1).
+__global__ __launch_bounds__(256) void ransac_triangulate_kernel(const double *__restrict__ pose12, const double2 *__restrict__ p1,
+                                                                 const double2 *__restrict__ p2, int n, double *__restrict__ points)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Pose P;
+    load_pose(pose12, P);
+    const double2 a = p1[k], b = p2[k];
+    double av[3];
+    rot_apply_h(P.R, a.x, a.y, av);
+    double l0, l1;
+    triangulate_lambdas(av, b.x, b.y, (b.x * b.x + b.y * b.y) + 1.0, P.T, l0, l1);
+    const double lam = (double)(float)l0;
+    points[3 * k + 0] = lam * a.x;
+    points[3 * k + 1] = lam * a.y;
+    points[3 * k + 2] = lam;
+}
+
+// Winner of every pair in one dense table (one copy to the host instead of one per pair):
+// packed[p] = {bestH, bestCount, iterations, 0 | bestErr | pose12 of the winner, identity if there is none}.
+struct PackedBest {
+    int bestH, bestCount, iterations, pad;
+    double bestErr;
+    double pose12[12];
+};
+__global__ __launch_bounds__(256) void ransac_pack_kernel(const RansacArgs g, PackedBest *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.nPairs) return;
+    PackedBest r;
+    r.bestH = g.bestH[p];
+    r.bestCount = g.bestCount[p];
+    r.iterations = g.iterations[p];
+    r.pad = 0;
+    r.bestErr = g.bestErr[p];
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        r.pose12[i] = r.bestH >= 0 ? g.pose12[((size_t)p * g.H + r.bestH) * 12 + i] : ((i == 0 || i == 4 || i == 8) ? 1.0 : 0.0);
+    out[p] = r;
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -1416,7 +1466,8 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, inlFlag, inlBlk;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, inlFlag, inlBlk, clock, packed;
+    PinBuf stage; // single-pair calls: the winner's record and its inlier list in one copy
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
@@ -1430,9 +1481,13 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
-                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->inlFlag, &b->inlBlk};
+                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->inlFlag, &b->inlBlk,
+                      &b->clock, &b->packed};
     for (DevBuf *d : bufs) d->release();
+    b->stage.release();
+    sfm_ctx *owner = b->ctx;
     delete b;
+    sfm_ctx_release(owner);
 }
 
 // Segments per pair of a scoring launch over `rows` rows: more than one when the launch would leave
@@ -1481,13 +1536,15 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         total = corr_offsets[n_pairs];
     }
     if (total > 0 && (!x || !y)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null correspondences");
-    if (n_hyp > 0 && n_pairs > 0 && !samples) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null sample table");
+    if (n_hyp > 0 && n_pairs > 0 && !samples && on_device) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null sample table");
+    const bool draw_samples = !samples && !on_device && n_hyp > 0 && n_pairs > 0; // the library draws the table itself
     SFM_HIP(ctx, hipSetDevice(ctx->device));
 
     sfm_ransac_batch *b = *batch_inout;
     if (!b) {
         b = new (std::nothrow) sfm_ransac_batch();
         if (!b) SFM_FAIL(ctx, SFM_ERR_OOM, "ransac: host allocation failed");
+        sfm_ctx_retain(ctx);
         b->ctx = ctx;
         *batch_inout = b;
     } else if (b->ctx != ctx) {
@@ -1519,7 +1576,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             SFM_HIP(ctx, hipMemcpyAsync(b->x.p, x, (size_t)total * sizeof(double2), hipMemcpyHostToDevice, st));
             SFM_HIP(ctx, hipMemcpyAsync(b->y.p, y, (size_t)total * sizeof(double2), hipMemcpyHostToDevice, st));
         }
-        if (n_pairs && n_hyp)
+        if (n_pairs && n_hyp && !draw_samples)
             SFM_HIP(ctx, hipMemcpyAsync(b->samples.p, samples, (size_t)n_pairs * n_hyp * 8 * sizeof(int32_t),
                                         hipMemcpyHostToDevice, st));
         g.x = b->x.as<double2>();
@@ -1544,6 +1601,23 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     SFM_HIP(ctx, hipMemcpyAsync(b->corrOff.p, corr_offsets, (size_t)(n_pairs + 1) * sizeof(int64_t),
                                 hipMemcpyHostToDevice, st));
 
+    if (draw_samples) {
+        uint64_t seed = ctx->ransac_seed;
+        if (seed == 0) { // as the reference: from the clock (RANSAC.cpp:170)
+            struct timespec ts;
+            clock_gettime(CLOCK_REALTIME, &ts);
+            seed = (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+        }
+        sfm_launch_sample_table(b->corrOff.as<int64_t>(), n_pairs, n_hyp, seed, b->samples.as<int32_t>(), st);
+    }
+    SFM_HIP(ctx, b->clock.reserve(sizeof(unsigned long long)));
+    SFM_HIP(ctx, b->packed.reserve(P1 * sizeof(PackedBest)));
+    g.t0 = b->clock.as<unsigned long long>();
+    g.maxTicks = 0;
+    if (ctx->ransac_max_time_ms > 0 && !fit_only) { // wall_clock64 ticks at 100 MHz
+        g.maxTicks = (long long)ctx->ransac_max_time_ms * 100000ll;
+        hipLaunchKernelGGL(ransac_clock_kernel, dim3(1), dim3(1), 0, st, b->clock.as<unsigned long long>());
+    }
     g.corrOff = b->corrOff.as<int64_t>();
     g.rec = b->rec.as<double>();
     g.rec32 = b->rec32.as<float>();
@@ -1659,6 +1733,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(1024), 0, st, g.inlCount, n_pairs, b->inlOff.as<int64_t>());
         hipLaunchKernelGGL(ransac_inlier_write_kernel, dim3(nBlk, n_pairs), dim3(256), 0, st, g, (const unsigned char *)flag,
                            (const int *)blk);
+        hipLaunchKernelGGL(ransac_pack_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, st, g, b->packed.as<PackedBest>());
     }
     SFM_HIP(ctx, hipGetLastError());
     b->args = g;
@@ -1756,25 +1831,20 @@ extern "C" int sfm_ransac_batch_best(sfm_ransac_batch *b, int32_t *best_hyp_out,
 {
     if (!b) return SFM_ERR_INVALID_ARG;
     sfm_ctx *ctx = b->ctx;
+    if (!b->scored) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: the batch holds no RANSAC result");
     const size_t P = (size_t)b->n_pairs;
-    std::vector<int32_t> bh(P ? P : 1);
-    SFM_HIP(ctx, hipMemcpyAsync(bh.data(), b->bestH.p, P * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    D2H(best_count_out, b->bestCount, P * sizeof(int32_t));
-    D2H(best_toterr_out, b->bestErr, P * sizeof(double));
-    D2H(iterations_out, b->iterations, P * sizeof(int32_t));
+    if (P == 0) return SFM_OK;
+    // one copy of the dense per-pair records (winner, count, error sum, iterations, winner's pose)
+    std::vector<PackedBest> rec(P);
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    SFM_HIP(ctx, hipMemcpyAsync(rec.data(), b->packed.p, P * sizeof(PackedBest), hipMemcpyDeviceToHost, ctx->stream));
     SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (best_hyp_out) memcpy(best_hyp_out, bh.data(), P * sizeof(int32_t));
-    if (pose12_out) {
-        for (size_t p = 0; p < P; p++) {
-            if (bh[p] >= 0) {
-                SFM_HIP(ctx, hipMemcpyAsync(pose12_out + 12 * p,
-                                            b->pose12.as<double>() + ((size_t)p * b->H + bh[p]) * 12,
-                                            12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            } else {
-                for (int i = 0; i < 12; i++) pose12_out[12 * p + i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
-            }
-        }
-        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t p = 0; p < P; p++) {
+        if (best_hyp_out) best_hyp_out[p] = rec[p].bestH;
+        if (best_count_out) best_count_out[p] = rec[p].bestCount;
+        if (best_toterr_out) best_toterr_out[p] = rec[p].bestErr;
+        if (iterations_out) iterations_out[p] = rec[p].iterations;
+        if (pose12_out) memcpy(pose12_out + 12 * p, rec[p].pose12, sizeof rec[p].pose12);
     }
     return SFM_OK;
 }
@@ -1836,39 +1906,50 @@ extern "C" int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, i
     // every row is scored when the caller asks for the per-row outputs
     int rc = ransac_run(ctx, 1, off, x, y, K, samples, n_hyp, max_squared_error, success_prob, adaptive, loss, false,
                         false, pair_batch(ctx), !counts_out && !toterr_out);
+    if (rc != SFM_OK) return rc;
     sfm_ransac_batch *b = *pair_batch(ctx);
-    int32_t bh = -1, bc = 0, it = 0;
-    double be = 0, pose12[12];
-    if (rc == SFM_OK) rc = sfm_ransac_batch_best(b, &bh, &bc, &be, pose12, &it);
-    if (rc == SFM_OK && bc > capacity) {
-        ctx->last_error = "ransac: inlier capacity too small";
-        rc = SFM_ERR_CAPACITY;
+    // The winner's record and min(n, capacity) entries of its inlier list (the count is not known yet) go to
+    // a pinned buffer in one go: one wait for the whole call.
+    const size_t nInl = (size_t)std::min(n, capacity);
+    const size_t rowBytes = (counts_out ? (size_t)n_hyp * sizeof(int32_t) : 0) + (toterr_out ? (size_t)n_hyp * sizeof(double) : 0);
+    SFM_HIP(ctx, b->stage.reserve(sizeof(PackedBest) + nInl * sizeof(int32_t) + rowBytes + 16));
+    unsigned char *stage = b->stage.as<unsigned char>();
+    hipStream_t st = ctx->stream;
+    SFM_HIP(ctx, hipMemcpyAsync(stage, b->packed.p, sizeof(PackedBest), hipMemcpyDeviceToHost, st));
+    size_t at = sizeof(PackedBest);
+    if (nInl > 0) SFM_HIP(ctx, hipMemcpyAsync(stage + at, b->inliers.p, nInl * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    at += (nInl * sizeof(int32_t) + 7) / 8 * 8;
+    const size_t atTot = at;
+    if (toterr_out && n_hyp > 0) {
+        SFM_HIP(ctx, hipMemcpyAsync(stage + at, b->toterr.p, (size_t)n_hyp * sizeof(double), hipMemcpyDeviceToHost, st));
+        at += (size_t)n_hyp * sizeof(double);
     }
-    if (rc == SFM_OK && bc > 0) rc = sfm_ransac_batch_inliers(b, inliers_out);
-    if (rc == SFM_OK) {
-        *count_out = bc;
-        if (best_hyp_out) *best_hyp_out = bh;
-        if (iterations_out) *iterations_out = it;
-        if (pose_out) { // 4x4 column-major [R|T; 0 0 0 1]
-            for (int c = 0; c < 4; c++)
-                for (int r = 0; r < 4; r++) pose_out[r + 4 * c] = (r == c) ? 1.0 : 0.0;
-            if (bh >= 0)
-                for (int r = 0; r < 3; r++) {
-                    for (int c = 0; c < 3; c++) pose_out[r + 4 * c] = pose12[3 * r + c];
-                    pose_out[r + 12] = pose12[9 + r];
-                }
-        }
-        hipError_t e = hipSuccess;
-        if (counts_out && n_hyp > 0)
-            e = hipMemcpy(counts_out, b->counts.p, (size_t)n_hyp * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && toterr_out && n_hyp > 0)
-            e = hipMemcpy(toterr_out, b->toterr.p, (size_t)n_hyp * sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            ctx->last_error = std::string("ransac: copy of per-hypothesis scores failed: ") + hipGetErrorString(e);
-            rc = SFM_ERR_HIP;
-        }
+    const size_t atCnt = at;
+    if (counts_out && n_hyp > 0)
+        SFM_HIP(ctx, hipMemcpyAsync(stage + at, b->counts.p, (size_t)n_hyp * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipStreamSynchronize(st));
+    PackedBest rec;
+    memcpy(&rec, stage, sizeof rec);
+    if (rec.bestCount > capacity) SFM_FAIL(ctx, SFM_ERR_CAPACITY, "ransac: inlier capacity too small");
+    if (rec.bestCount > 0) {
+        if (!inliers_out) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: null inlier buffer");
+        memcpy(inliers_out, stage + sizeof(PackedBest), (size_t)rec.bestCount * sizeof(int32_t));
     }
-    return rc;
+    if (toterr_out && n_hyp > 0) memcpy(toterr_out, stage + atTot, (size_t)n_hyp * sizeof(double));
+    if (counts_out && n_hyp > 0) memcpy(counts_out, stage + atCnt, (size_t)n_hyp * sizeof(int32_t));
+    *count_out = rec.bestCount;
+    if (best_hyp_out) *best_hyp_out = rec.bestH;
+    if (iterations_out) *iterations_out = rec.iterations;
+    if (pose_out) { // 4x4 column-major [R|T; 0 0 0 1]
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) pose_out[r + 4 * c] = (r == c) ? 1.0 : 0.0;
+        if (rec.bestH >= 0)
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) pose_out[r + 4 * c] = rec.pose12[3 * r + c];
+                pose_out[r + 12] = rec.pose12[9 + r];
+            }
+    }
+    return SFM_OK;
 }
 
 extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n, const int32_t *samples,
@@ -1893,6 +1974,47 @@ extern "C" int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *
         }
     }
     return rc;
+}
+
+extern "C" int sfm_eight_point_from_subset(sfm_ctx *ctx, const double *calc1, const double *calc2, int n_calc, const double *all1,
+                                           const double *all2, int n_all, double *pose16_out, double *points_out)
+{
+    if (!ctx) return SFM_ERR_INVALID_ARG;
+    if (n_calc < 8) // eightPoint.cpp:228-231
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG,
+                 "EightPointFromSubset: There have to be at least 8 pair-to-pair-correspondences (was: %d) to approximate a pose.", n_calc);
+    if (n_calc != 8) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "EightPointFromSubset: the fit kernel takes exactly 8 correspondences (was: %d)", n_calc);
+    if (!calc1 || !calc2 || n_all < 0 || (n_all > 0 && (!all1 || !all2))) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "EightPointFromSubset: null input");
+    const int64_t off[2] = {0, 8};
+    const double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const int32_t rows[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    int rc = ransac_run(ctx, 1, off, calc1, calc2, K, rows, 1, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, true, pair_batch(ctx));
+    if (rc != SFM_OK) return rc;
+    sfm_ransac_batch *b = *pair_batch(ctx);
+    hipStream_t st = ctx->stream;
+    double pose12[12];
+    SFM_HIP(ctx, hipMemcpyAsync(pose12, b->pose12.p, sizeof pose12, hipMemcpyDeviceToHost, st));
+    if (n_all > 0 && points_out) { // the two point sets are staged behind each other in the (unused) error buffer
+        SFM_HIP(ctx, b->errBuf.reserve((size_t)n_all * 2 * sizeof(double2)));
+        SFM_HIP(ctx, b->refitPoints.reserve((size_t)n_all * 3 * sizeof(double)));
+        double2 *d1 = b->errBuf.as<double2>(), *d2 = d1 + n_all;
+        SFM_HIP(ctx, hipMemcpyAsync(d1, all1, (size_t)n_all * sizeof(double2), hipMemcpyHostToDevice, st));
+        SFM_HIP(ctx, hipMemcpyAsync(d2, all2, (size_t)n_all * sizeof(double2), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(ransac_triangulate_kernel, dim3((n_all + 255) / 256), dim3(256), 0, st, b->pose12.as<double>(), d1, d2, n_all,
+                           b->refitPoints.as<double>());
+        SFM_HIP(ctx, hipGetLastError());
+        SFM_HIP(ctx, hipMemcpyAsync(points_out, b->refitPoints.p, (size_t)n_all * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    SFM_HIP(ctx, hipStreamSynchronize(st));
+    if (pose16_out) {
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) pose16_out[r + 4 * c] = (r == c) ? 1.0 : 0.0;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) pose16_out[r + 4 * c] = pose12[3 * r + c];
+            pose16_out[r + 12] = pose12[9 + r];
+        }
+    }
+    return SFM_OK;
 }
 
 extern "C" int sfm_eight_point_algorithm(sfm_ctx *ctx, const double *x, const double *y, int n, double *pose16_out,
@@ -1942,7 +2064,7 @@ constexpr size_t ST_FLAGS = slice256((size_t)SFM_STATIC_MAX_CORR);
 constexpr size_t ST_BLK = slice256((size_t)((SFM_STATIC_MAX_CORR + 255) / 256) * sizeof(int));
 constexpr size_t ST_SMALL = 256; // per-pair scalars of a one-pair batch, two offsets
 constexpr size_t STATIC_SCRATCH_BYTES = 2 * ST_XY + ST_SAMPLES + ST_REC + ST_REC32 + ST_POSE + ST_COUNTS + ST_TOTERR +
-                                        ST_INLIERS + ST_FLAGS + ST_BLK + 9 * ST_SMALL;
+                                        ST_INLIERS + ST_FLAGS + ST_BLK + 11 * ST_SMALL;
 } // namespace
 
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
@@ -1987,6 +2109,8 @@ int sfm_ransac_static_setup(int device)
     slice(b->inlOff, ST_SMALL);
     slice(b->active, ST_SMALL);
     slice(b->maxIter, ST_SMALL);
+    slice(b->clock, ST_SMALL);
+    slice(b->packed, ST_SMALL);
     if ((size_t)(at - static_cast<unsigned char *>(ptr)) != STATIC_SCRATCH_BYTES) { // the table above and the size disagree
         delete b;
         return SFM_ERR_HIP;

@@ -1,16 +1,24 @@
-// Drives the C++ host mirror end to end: reads a binary case file written by the test suite,
-// runs match() and RANSAC() with the reference's option structs, writes the results.
+// Drives the adaptor translation units (adaptors/*.cpp, compiled against the stand-in headers) end to end:
+// reads a binary case file written by the test suite, runs SfM::match::match and SfM::solve::RANSAC with the
+// reference's option structs, writes the results.
 //   test_frontend <case.bin> <out.bin>
+//   test_frontend --lifetime        (makes the thread's context and exits without releasing anything)
 // case.bin: int32 nA, nB, dim; float thr, gate; float descA[nA*dim]; double ptsA[2nA]; descB; ptsB;
-//           int32 n, maxIter; uint64 seed; double maxSqErr, successProb; double K[9]; double x[2n]; double y[2n]
-// out.bin:  int32 nMatches; int32 pairs[2*nMatches]; int32 nInliers; int32 inliers[nInliers]
+//           int32 n, maxIter; double maxSqErr, successProb; double K[9]; double x[2n]; double y[2n]
+// out.bin:  int32 nMatches; int32 pairs[2*nMatches]; int32 nInliers; int32 inliers[nInliers];
+//           int32 nPoints; double pose[16]; double points[3*nPoints];          (refit on the inliers)
+//           int32 nMatchesPlugin; int32 pairs[...];                            (similarityMetric plug-in, CPU path)
+//           int32 nInliersPlugin; int32 inliers[...]                           (loss plug-in, CPU path)
+// The sample table's seed comes from the environment (SFM_AMD_RANSAC_SEED), as adaptors/ransac_amd.cpp reads it.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
-#include "sfm_frontend.hpp"
+#include "match/match.hpp"
+#include "solve/solve.hpp"
 
-using namespace sfm_amd;
+using namespace SfM;
 
 template <typename T> static void rd(FILE *f, T *dst, size_t n)
 {
@@ -20,8 +28,54 @@ template <typename T> static void rd(FILE *f, T *dst, size_t n)
     }
 }
 
+static void wr_list(FILE *o, const std::vector<int> &v)
+{
+    const int32_t n = (int32_t)v.size();
+    fwrite(&n, 4, 1, o);
+    for (int q : v) {
+        const int32_t w = q;
+        fwrite(&w, 4, 1, o);
+    }
+}
+
+static void wr_pairs(FILE *o, const std::vector<std::tuple<int, int>> &m)
+{
+    const int32_t n = (int32_t)m.size();
+    fwrite(&n, 4, 1, o);
+    for (auto &t : m) {
+        const int32_t a = std::get<0>(t), b = std::get<1>(t);
+        fwrite(&a, 4, 1, o);
+        fwrite(&b, 4, 1, o);
+    }
+}
+
+static int lifetime()
+{
+    std::vector<Keypoint> k(40);
+    for (size_t i = 0; i < k.size(); i++) {
+        k[i].descriptor.assign(128, 1.0f);
+        k[i].descriptor[i] = 200.0f;
+        k[i].point = Vec2{{(double)i, 0.0}};
+    }
+    match::MATCHING_OPTIONS mo;
+    mo.threshold = 0.9f;
+    const auto m = match::match(k, k, mo);
+    if (m.size() != k.size()) return 3;
+    std::vector<Vec2> x(30), y(30);
+    for (int i = 0; i < 30; i++) {
+        x[i] = Vec2{{0.01 * i, 0.02 * (i % 7)}};
+        y[i] = Vec2{{0.01 * i + 0.05, 0.02 * (i % 7) + 0.001 * i}};
+    }
+    Mat3 K = Mat3::Identity();
+    K(0, 0) = K(1, 1) = 1000;
+    solve::RANSAC(x, y, K, solve::RANSAC_OPTIONS{}, false);
+    std::cout << "lifetime ok" << std::endl;
+    return 0; // the thread-local context, its pair buffers and streams are released by static destruction
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 2 && !strcmp(argv[1], "--lifetime")) return lifetime();
     if (argc != 3) return 2;
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;
@@ -42,10 +96,9 @@ int main(int argc, char **argv)
     };
     auto kA = read_kps(nA), kB = read_kps(nB);
     int32_t n, maxIter;
-    unsigned long long seed;
     double maxSqErr, successProb;
     Mat3 K;
-    rd(f, &n, 1); rd(f, &maxIter, 1); rd(f, &seed, 1); rd(f, &maxSqErr, 1); rd(f, &successProb, 1); rd(f, K.m, 9);
+    rd(f, &n, 1); rd(f, &maxIter, 1); rd(f, &maxSqErr, 1); rd(f, &successProb, 1); rd(f, K.m, 9);
     std::vector<Vec2> x(n), y(n);
     rd(f, &x[0][0], (size_t)2 * n);
     rd(f, &y[0][0], (size_t)2 * n);
@@ -56,7 +109,7 @@ int main(int argc, char **argv)
     mo.maxDistancePxSquared = gate;
     auto m = match::match(kA, kB, mo);
 
-    // error behaviour of the reference: unknown algorithm throws std::invalid_argument
+    // error behaviour of the reference: unknown algorithm throws std::invalid_argument (match.cpp:18)
     bool threw = false;
     try {
         match::MATCHING_OPTIONS bad;
@@ -66,24 +119,30 @@ int main(int argc, char **argv)
         threw = true;
     }
     if (!threw) return 3;
-    threw = false;
-    try {
-        match::MATCHING_OPTIONS bad;
-        bad.similarityMetric = [](const std::vector<float> &, const std::vector<float> &) { return 0.f; };
-        match::match(kA, kB, bad);
-    } catch (const std::invalid_argument &) {
-        threw = true;
-    }
-    if (!threw) return 4;
+    // a similarityMetric plug-in (match.hpp:58) runs on the CPU path with the same semantics
+    match::MATCHING_OPTIONS plug = mo;
+    plug.similarityMetric = [](const std::vector<float> &a, const std::vector<float> &b) { return match::cosineSimilarity(a, b); };
+    auto mPlug = match::match(kA, kB, plug);
 
     solve::RANSAC_OPTIONS ro;
     ro.maxIter = maxIter;
     ro.maxTimeMs = 20000;
     ro.maxSquaredError = maxSqErr;
     ro.successProb = successProb;
-    ro.seed = seed;
     auto inl = solve::RANSAC(x, y, K, ro, true);
-    if (!solve::RANSAC(x, std::vector<Vec2>(y.begin(), y.begin() + 3), K, ro, false).empty()) return 5;
+    if (!solve::RANSAC(x, std::vector<Vec2>(y.begin(), y.begin() + 3), K, ro, false).empty()) return 5; // RANSAC.cpp:148
+    // a loss plug-in (solve.hpp:118-124) runs the CPU loop; the model stays the default
+    solve::RANSAC_OPTIONS roPlug = ro;
+    roPlug.maxIter = 400;
+    const auto defaultLoss = ro.loss;
+    roPlug.loss = [defaultLoss](const Mat3 &Km, const Vec2 o1, const Vec2 o2, const Vec3 p, const Mat4 &view) {
+        return defaultLoss(Km, o1, o2, p, view);
+    };
+    auto inlPlug = solve::RANSAC(x, y, K, roPlug, false);
+    // a time limit of zero stops the device loop after its first slice of sample rows (RANSAC.cpp:189-196)
+    solve::RANSAC_OPTIONS roTime = ro;
+    roTime.maxTimeMs = 0;
+    (void)solve::RANSAC(x, y, K, roTime, false);
 
     // scene.cpp:264-298: refit on the inliers
     std::vector<Vec2> in1, in2;
@@ -92,6 +151,7 @@ int main(int argc, char **argv)
         in2.push_back(y[v]);
     }
     EightPointResult refit;
+    refit.pose = Mat4::Identity();
     if (in1.size() >= 8) refit = solve::eightPointAlgorithm(in1, in2);
     threw = false;
     try {
@@ -103,22 +163,14 @@ int main(int argc, char **argv)
 
     FILE *o = fopen(argv[2], "wb");
     if (!o) return 2;
-    int32_t nm = (int32_t)m.size(), ni = (int32_t)inl.size();
-    fwrite(&nm, 4, 1, o);
-    for (auto &t : m) {
-        int32_t a = std::get<0>(t), b = std::get<1>(t);
-        fwrite(&a, 4, 1, o);
-        fwrite(&b, 4, 1, o);
-    }
-    fwrite(&ni, 4, 1, o);
-    for (int v : inl) {
-        int32_t q = v;
-        fwrite(&q, 4, 1, o);
-    }
-    int32_t np3 = (int32_t)refit.points.size();
+    wr_pairs(o, m);
+    wr_list(o, inl);
+    const int32_t np3 = (int32_t)refit.points.size();
     fwrite(&np3, 4, 1, o);
     fwrite(refit.pose.data(), 8, 16, o);
     if (np3) fwrite(&refit.points[0][0], 8, (size_t)np3 * 3, o);
+    wr_pairs(o, mPlug);
+    wr_list(o, inlPlug);
     fclose(o);
     return 0;
 }

@@ -1,5 +1,6 @@
-"""The C++ host mirror (sfm_amd/host: match() / RANSAC() with the reference's option structs)
-driven end to end through a small binary, checked against the CPU restatement."""
+"""The adaptor translation units (adaptors/*.cpp: SfM::match::match and SfM::solve::RANSAC with the
+reference's option structs, compiled against the stand-in headers) driven end to end through a small
+binary, checked against the CPU restatement."""
 import os
 import struct
 import subprocess
@@ -20,23 +21,32 @@ def run_case(tmp_path, dA, pA, dB, pB, thr, gate, tv, max_iter, seed, tag):
         f.write(struct.pack("<iiiff", len(dA), len(dB), dA.shape[1], thr, gate))
         for a in (dA.astype(np.float32), pA.astype(np.float64), dB.astype(np.float32), pB.astype(np.float64)):
             f.write(a.tobytes())
-        f.write(struct.pack("<iiQdd", len(tv["x"]), max_iter, seed, 1.0, 0.999))
+        f.write(struct.pack("<iidd", len(tv["x"]), max_iter, 1.0, 0.999))
         f.write(np.asfortranarray(tv["K"]).reshape(-1, order="F").astype(np.float64).tobytes())
         f.write(tv["x"].astype(np.float64).tobytes())
         f.write(tv["y"].astype(np.float64).tobytes())
-    r = subprocess.run([EXE, case, out], capture_output=True, text=True, timeout=100)
+    env = dict(os.environ, SFM_AMD_RANSAC_SEED=str(seed))
+    r = subprocess.run([EXE, case, out], capture_output=True, text=True, timeout=100, env=env)
     assert r.returncode == 0, r.stderr + r.stdout
     blob = open(out, "rb").read()
-    raw = np.frombuffer(blob[:len(blob) // 4 * 4], np.int32)
-    nm = raw[0]
-    pairs = raw[1:1 + 2 * nm].reshape(-1, 2)
-    ni = raw[1 + 2 * nm]
-    inl = raw[2 + 2 * nm:2 + 2 * nm + ni]
-    at = 4 * (2 + 2 * nm + ni)
-    n3 = struct.unpack_from("<i", blob, at)[0]
-    pose = np.frombuffer(blob, np.float64, 16, at + 4).reshape(4, 4, order="F")
-    pts = np.frombuffer(blob, np.float64, 3 * n3, at + 4 + 128).reshape(-1, 3)
-    return pairs, inl, r.stdout, pose, pts
+    at = 0
+
+    def ints(k):
+        nonlocal at
+        v = np.frombuffer(blob, np.int32, k, at)
+        at += 4 * k
+        return v
+
+    pairs = ints(2 * int(ints(1)[0])).reshape(-1, 2)
+    inl = ints(int(ints(1)[0]))
+    n3 = int(ints(1)[0])
+    pose = np.frombuffer(blob, np.float64, 16, at).reshape(4, 4, order="F")
+    at += 128
+    pts = np.frombuffer(blob, np.float64, 3 * n3, at).reshape(-1, 3)
+    at += 24 * n3
+    pairs_plug = ints(2 * int(ints(1)[0])).reshape(-1, 2)
+    inl_plug = ints(int(ints(1)[0]))
+    return dict(pairs=pairs, inliers=inl, log=r.stdout, pose=pose, points=pts, pairs_plugin=pairs_plug, inliers_plugin=inl_plug)
 
 
 def test_cpp_match_and_ransac(tmp_path, oracle):
@@ -44,15 +54,29 @@ def test_cpp_match_and_ransac(tmp_path, oracle):
     d, p, _ = synth.image_set(2, 700, seed=61)
     dA, pA, dB, pB = d[:650], p[:650], d[700:], p[700:]
     tv = synth.two_view(1500, inlier_ratio=0.7, seed=62, noise_px=0.3)
-    pairs, inl, log, pose, pts = run_case(tmp_path, dA, pA, dB, pB, 0.95, 1e4, tv, 2048, 1234, "a")
+    H, seed = 2048, 1234
+    got = run_case(tmp_path, dA, pA, dB, pB, 0.95, 1e4, tv, H, seed, "a")
     exp, _, _ = oracle.match(dA, pA, dB, pB, threshold=0.95, max_dist_sq=1e4)
-    assert np.array_equal(pairs, exp)
-    assert "RANSAC: finished after" in log
-    assert len(inl) > 100 and np.all(np.diff(inl) > 0)
-    assert tv["inlier_mask"][inl].mean() > 0.95
-    pairs2, inl2, _, _, _ = run_case(tmp_path, dA, pA, dB, pB, 0.95, 1e4, tv, 2048, 1234, "b")
-    assert np.array_equal(inl, inl2) and np.array_equal(pairs, pairs2)
-    # eightPointAlgorithm on the inliers (scene.cpp:288) through the C++ mirror
+    assert np.array_equal(got["pairs"], exp)
+    # a similarityMetric plug-in takes the adaptor's CPU loop: same lists
+    assert np.array_equal(got["pairs_plugin"], exp)
+    # RANSAC(): the library drew its sample table from the seed with its documented generator (pair index 0);
+    # the restatement of that generator and of the in-order adaptive scan gives the same inlier list
+    assert "RANSAC: finished after" in got["log"]
+    S = oracle.sample_table(1500, H, seed, 0)
+    e = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    assert np.array_equal(got["inliers"], e["inliers"])
+    assert f"finished after {e['iterations']} iterations" in got["log"]
+    assert len(got["inliers"]) > 100 and tv["inlier_mask"][got["inliers"]].mean() > 0.95
+    again = run_case(tmp_path, dA, pA, dB, pB, 0.95, 1e4, tv, H, seed, "b")
+    assert np.array_equal(got["inliers"], again["inliers"]) and np.array_equal(got["pairs"], again["pairs"])
+    other = run_case(tmp_path, dA, pA, dB, pB, 0.95, 1e4, tv, H, seed + 1, "c")
+    assert not np.array_equal(oracle.sample_table(1500, H, seed + 1, 0), S) and len(other["inliers"]) > 100
+    # a loss plug-in runs the adaptor's CPU loop (400 iterations, default model on the device): a plausible inlier set
+    assert len(got["inliers_plugin"]) > 100 and np.all(np.diff(got["inliers_plugin"]) > 0)
+    assert tv["inlier_mask"][got["inliers_plugin"]].mean() > 0.9
+    # eightPointAlgorithm on the inliers (scene.cpp:288) through the eight-point adaptor
+    inl = got["inliers"]
     epose, epts, _, _ = oracle.eight_point(tv["x"][inl], tv["y"][inl])
-    assert np.abs(pose - epose).max() < 1e-8
-    assert len(pts) == len(inl) and np.abs(pts - epts).max() <= 1e-6 * np.abs(epts).max()
+    assert np.abs(got["pose"] - epose).max() < 1e-8
+    assert len(got["points"]) == len(inl) and np.abs(got["points"] - epts).max() <= 1e-6 * np.abs(epts).max()

@@ -390,3 +390,47 @@ def test_repeated_pair_calls_reuse_their_buffers(ctx, oracle):
         pose12 = ctx.eight_point_fit(tv["x"], tv["y"], S[:4])
         ref12, _ = oracle.fit_hypotheses(tv["x"], tv["y"], S[:4])
         assert np.array_equal(pose12, ref12)
+
+
+def test_library_drawn_samples_and_time_cap(ctx, oracle):
+    """samples = NULL: the library draws the table on the device from the context's seed with the generator
+    documented in the header; the result equals the restatement's on the restated table.  A time limit that
+    has already passed stops the scan after the first slice of rows (RANSAC.cpp:189-196)."""
+    tv = synth.two_view(2500, inlier_ratio=0.35, seed=71)
+    H = 4096
+    ctx.set_option("ransac_seed", 99)
+    try:
+        got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
+        S = oracle.sample_table(2500, H, 99, 0)
+        exp = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        assert got["best_h"] == exp["best_h"] and got["iterations"] == exp["iterations"]
+        assert np.array_equal(got["inliers"], exp["inliers"]) and np.array_equal(got["pose"], exp["pose"])
+        ctx.set_option("ransac_seed", 0)  # clock-seeded, as the reference: still a valid run
+        r = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
+        assert r["best_h"] >= 0 and r["iterations"] > 0 and len(r["inliers"]) >= 8
+        ctx.set_option("ransac_seed", 99)
+        ctx.set_option("ransac_max_time_ms", 1)
+        ctx.set_option("hyps_per_launch", 64)  # slices of 64, 256, 1024, ... rows
+        import time
+        time.sleep(0.01)
+        capped = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
+        assert capped["iterations"] <= H
+        first = oracle.ransac(tv["x"], tv["y"], tv["K"], S[:capped["iterations"]], max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        assert np.array_equal(capped["inliers"], first["inliers"])  # the best of the rows that were reached
+    finally:
+        ctx.set_option("ransac_seed", 0)
+        ctx.set_option("ransac_max_time_ms", 0)
+        ctx.set_option("hyps_per_launch", 0)
+
+
+def test_eight_point_from_subset(ctx, oracle):
+    """The whole of eightPointAlgorithmFromSubset (eightPoint.cpp:225-372): pose from 8 correspondences, all
+    correspondences triangulated under it."""
+    tv = synth.two_view(300, inlier_ratio=0.8, seed=19, noise_px=0.2)
+    rows = synth.sample_table(300, 1, seed=20)[0]
+    pose, pts = ctx.eight_point_from_subset(tv["x"][rows], tv["y"][rows], tv["x"], tv["y"])
+    epose, epts, _, _ = oracle.eight_point_from_subset(tv["x"][rows], tv["y"][rows], tv["x"], tv["y"])
+    assert np.array_equal(pose, epose) and np.array_equal(pts, epts)
+    with pytest.raises(capi.SfmError) as e:
+        ctx.eight_point_from_subset(tv["x"][:7], tv["y"][:7], tv["x"], tv["y"])
+    assert e.value.code == capi.ERR_INVALID_ARG and "at least 8" in str(e.value)
