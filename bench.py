@@ -265,8 +265,9 @@ def main():
         ctx.set_option("sim_variant", sim_variant)
 
     # ---- CPU baseline (rank 0, N = 1) ----------------------------------------------------------
+    pipe_inputs = out.get("pipeline", {}).pop("_cpu_inputs", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, desc, pts, out.get("ransac"))
+        out["cpu_baseline"] = cpu_baseline(args, desc, pts, out.get("ransac"), pipe_inputs)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -425,6 +426,27 @@ def bench_pipeline(ctx, args):
     stage_ms /= reps
     best = batch.best()
     total = float(stage_ms.sum())
+    # The reference's own call pattern (scene.cpp:60, :261): one pair per call, host buffers in, lists out.
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    f0, f1 = slice(starts[0], starts[1]), slice(starts[1], starts[2])
+    cx, cy = corr.fetch()
+    coff = corr.offsets()
+    x0, y0 = cx[coff[0]:coff[1]], cy[coff[0]:coff[1]]
+    calls = 30  # steady state: the first dozen calls of a process run at half speed (clocks, runtime pools)
+    for _ in range(10):
+        ctx.match_pair(desc[f0], pts[f0], desc[f1], pts[f1], threshold=0.95, max_dist_sq=100.0 * 100.0)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        ctx.match_pair(desc[f0], pts[f0], desc[f1], pts[f1], threshold=0.95, max_dist_sq=100.0 * 100.0)
+    match_call_ms = (time.perf_counter() - t0) / calls * 1e3
+    ctx.set_option("ransac_seed", 20261111)
+    for _ in range(10):
+        ctx.ransac_pair(x0, y0, K, H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        rr = ctx.ransac_pair(x0, y0, K, H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
+    ransac_call_ms = (time.perf_counter() - t0) / calls * 1e3
+    ctx.set_option("ransac_seed", 0)
     out = {
         "workload": f"{frames} synthetic frames x {feats} features, {frames - 1} consecutive pairs, {H} hypotheses per pair",
         "ms": {"match": round(stage_ms[0], 3), "correspondences": round(stage_ms[1], 3),
@@ -433,7 +455,15 @@ def bench_pipeline(ctx, args):
         "matches_per_pair": round(res.total() / (frames - 1), 1),
         "mean_inliers": float(np.mean(best["count"])),
         "tracks": int(n_tracks), "points_averaged": int((chain["counts"] > 1).sum()),
+        "one_pair_per_call": {
+            "what": "the reference's call pattern: sfm_match_pair / sfm_ransac_pair once per frame pair, host buffers in "
+                    "(pageable), lists out; upload, ingest and download inside the time",
+            "match_pair_ms": round(match_call_ms, 3), "features": int(counts[0]),
+            "ransac_pair_ms": round(ransac_call_ms, 3), "correspondences": int(len(x0)), "hypotheses": H,
+            "ransac_iterations": int(rr["iterations"]), "ransac_inliers": int(len(rr["inliers"])),
+        },
     }
+    out["_cpu_inputs"] = (desc, pts, counts, pl, cx, cy, coff, K, H)
     s.close()
     return out
 
@@ -572,7 +602,7 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
     return out
 
 
-def cpu_baseline(args, desc, pts, ransac_out):
+def cpu_baseline(args, desc, pts, ransac_out, pipe_inputs=None):
     """The CPU restatement of the reference path (oracle/, OpenMP over all host threads the
     environment grants) on a bounded sample of the same workload."""
     from oracle import oracle_api as oracle
@@ -613,6 +643,28 @@ def cpu_baseline(args, desc, pts, ransac_out):
                                    f"the {nc} indices (RANSAC.cpp:201), the fit, the triangulation of every correspondence by "
                                    "column-pivoted QR and the loss; OpenMP over hypotheses in place of tbb::parallel_for; "
                                    "input generation included in the time (<5 %)"}
+    if pipe_inputs is not None:
+        # the default-run stand-in's 26 pairs through the restatement: match, then RANSAC on the same
+        # correspondences with the library's generator restated for the sample tables
+        fdesc, fpts, fcounts, fpl, cx, cy, coff, K, H = pipe_inputs
+        fstarts = np.concatenate([[0], np.cumsum(fcounts)])
+        t0 = time.perf_counter()
+        for a, b in fpl:
+            A, B = slice(fstarts[a], fstarts[a + 1]), slice(fstarts[b], fstarts[b + 1])
+            oracle.match(fdesc[A], fpts[A], fdesc[B], fpts[B], threshold=0.95, max_dist_sq=100.0 * 100.0)
+        tm = time.perf_counter() - t0
+        oracle.emulate_shuffle(True)
+        t0 = time.perf_counter()
+        for k in range(len(fpl)):
+            nk = int(coff[k + 1] - coff[k])
+            S = oracle.sample_table(nk, H, 20261111, k)
+            oracle.ransac(cx[coff[k]:coff[k + 1]], cy[coff[k]:coff[k + 1]], K, S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        tr = time.perf_counter() - t0
+        oracle.emulate_shuffle(False)
+        out["default_run_stand_in"] = {"pairs": int(len(fpl)), "match_ms": round(tm * 1e3, 1), "ransac_ms": round(tr * 1e3, 1),
+                                       "cores": threads, "kind": "port",
+                                       "note": "the restatement scores every row of the table and then replays the in-order scan; "
+                                               "the reference's loop stops at the adaptive cap, so its RANSAC time is lower"}
     return out
 
 

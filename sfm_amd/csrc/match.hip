@@ -1169,6 +1169,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
+    r->hostOut.release();
     sfm_ctx *owner = r->ctx;
     delete r;
     sfm_ctx_release(owner);
@@ -1622,27 +1623,34 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
     ctx->pair_set = set;
     const int32_t pl[2] = {0, 1};
     rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &ctx->pair_result, true);
+    if (rc != SFM_OK) return rc;
     sfm_match_result *res = ctx->pair_result;
+    // The count, min(nA, nB, capacity) entries of the list (the count is not known yet) and the optional
+    // per-row / per-column bests go to one pinned buffer: one wait for the whole call.
+    const size_t nList = (size_t)std::min(std::min(nA, nB), capacity);
+    const size_t b1 = matches1_out ? (size_t)nA * sizeof(int32_t) : 0, b2 = matches2_out ? (size_t)nB * sizeof(int32_t) : 0;
+    SFM_HIP(ctx, res->hostOut.reserve(16 + nList * sizeof(int2) + b1 + b2));
+    unsigned char *stage = res->hostOut.as<unsigned char>();
+    hipStream_t st = ctx->stream;
+    SFM_HIP(ctx, hipMemcpyAsync(stage, res->offsets.as<int64_t>() + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    size_t at = 16;
+    if (nList > 0) SFM_HIP(ctx, hipMemcpyAsync(stage + at, res->pairs.p, nList * sizeof(int2), hipMemcpyDeviceToHost, st));
+    at += nList * sizeof(int2);
+    if (b1) SFM_HIP(ctx, hipMemcpyAsync(stage + at, res->m1.p, b1, hipMemcpyDeviceToHost, st));
+    if (b2) SFM_HIP(ctx, hipMemcpyAsync(stage + at + b1, res->m2.p, b2, hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipStreamSynchronize(st));
     int64_t total = 0;
-    if (rc == SFM_OK) rc = sfm_match_result_total(res, &total);
-    if (rc == SFM_OK && total > capacity) {
-        ctx->last_error = "match: output capacity too small";
-        rc = SFM_ERR_CAPACITY;
+    memcpy(&total, stage, sizeof total);
+    res->total = total;
+    if (total > capacity) SFM_FAIL(ctx, SFM_ERR_CAPACITY, "match: output capacity too small");
+    if (total > 0) {
+        if (!pairs_out) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: null output list");
+        memcpy(pairs_out, stage + 16, (size_t)total * sizeof(int2));
     }
-    if (rc == SFM_OK && total > 0) rc = sfm_match_result_pairs(res, pairs_out);
-    if (rc == SFM_OK) {
-        *count_out = (int)total;
-        hipError_t e = hipSuccess;
-        if (matches1_out && nA > 0)
-            e = hipMemcpy(matches1_out, res->m1.p, (size_t)nA * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && matches2_out && nB > 0)
-            e = hipMemcpy(matches2_out, res->m2.p, (size_t)nB * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            ctx->last_error = std::string("match: copy of matches1/2 failed: ") + hipGetErrorString(e);
-            rc = SFM_ERR_HIP;
-        }
-    }
-    return rc;
+    if (b1) memcpy(matches1_out, stage + at, b1);
+    if (b2) memcpy(matches2_out, stage + at + b1, b2);
+    *count_out = (int)total;
+    return SFM_OK;
 }
 
 void sfm_pair_match_free(sfm_ctx *ctx)

@@ -79,7 +79,7 @@ struct sfm_match_result {
     DevBuf offsets; // int64[n_pairs+1]
     DevBuf pairs;   // int2[sum min(nA,nB)]
     DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2, kill;
-    PinBuf hostRecs, hostWork;
+    PinBuf hostRecs, hostWork, hostOut; // hostOut: staging of the single-pair entry point's outputs
     int64_t total = -1;
     hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
 };

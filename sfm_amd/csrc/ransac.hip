@@ -1467,7 +1467,8 @@ struct sfm_ransac_batch {
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
         inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, inlFlag, inlBlk, clock, packed;
-    PinBuf stage; // single-pair calls: the winner's record and its inlier list in one copy
+    PinBuf stage;   // single-pair calls: the winner's record and its inlier list in one copy
+    PinBuf stageIn; // and the two correspondence arrays on their way in
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
     bool scored = false;   // the last run went through selection (not fit-only)
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
@@ -1485,6 +1486,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
                       &b->clock, &b->packed};
     for (DevBuf *d : bufs) d->release();
     b->stage.release();
+    b->stageIn.release();
     sfm_ctx *owner = b->ctx;
     delete b;
     sfm_ctx_release(owner);
@@ -1572,7 +1574,17 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         SFM_HIP(ctx, b->x.reserve((size_t)(total ? total : 1) * sizeof(double2)));
         SFM_HIP(ctx, b->y.reserve((size_t)(total ? total : 1) * sizeof(double2)));
         SFM_HIP(ctx, b->samples.reserve(PH * 8 * sizeof(int32_t)));
-        if (total) {
+        if (total && !no_alloc && (size_t)total * sizeof(double2) <= ((size_t)1 << 20)) {
+            // small inputs (one pair of the reference's frame loop): both arrays through one pinned buffer, two
+            // copies that are asynchronous for real instead of two staged copies from pageable memory
+            const size_t bytes = (size_t)total * sizeof(double2);
+            SFM_HIP(ctx, b->stageIn.reserve(2 * bytes));
+            SFM_HIP(ctx, hipStreamSynchronize(st)); // the buffer may still feed the previous call's copies
+            memcpy(b->stageIn.p, x, bytes);
+            memcpy(b->stageIn.as<unsigned char>() + bytes, y, bytes);
+            SFM_HIP(ctx, hipMemcpyAsync(b->x.p, b->stageIn.p, bytes, hipMemcpyHostToDevice, st));
+            SFM_HIP(ctx, hipMemcpyAsync(b->y.p, b->stageIn.as<unsigned char>() + bytes, bytes, hipMemcpyHostToDevice, st));
+        } else if (total) {
             SFM_HIP(ctx, hipMemcpyAsync(b->x.p, x, (size_t)total * sizeof(double2), hipMemcpyHostToDevice, st));
             SFM_HIP(ctx, hipMemcpyAsync(b->y.p, y, (size_t)total * sizeof(double2), hipMemcpyHostToDevice, st));
         }
@@ -1674,9 +1686,11 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         int64_t h = 256 * std::max<int64_t>(1, (fill + n_pairs - 1) / n_pairs);
         if (!no_alloc && split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
         if (ctx->hyps_per_launch > 0) h = 64 * ((ctx->hyps_per_launch + 63) / 64); // caller's first slice
+        // (a single pair whose scan has stopped still pays a few microseconds for every later slice's
+        // launches: its slices grow by eight, a batch's by four)
         while (h < n_hyp && nBounds < 38) {
             bounds[nBounds++] = (int)h;
-            h *= 4;
+            h *= (n_pairs == 1) ? 8 : 4;
         }
     }
     bounds[nBounds++] = n_hyp;
