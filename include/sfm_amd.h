@@ -33,6 +33,7 @@ extern "C" {
  * (MATCHING_OPTIONS::similarityMetric holding anything else has no kernel.) */
 #define SFM_METRIC_COSINE 0
 #define SFM_METRIC_DOT 1
+#define SFM_METRIC_L2 2 /* extension, through sfm_match_batch_l2 only */
 
 /* match/match.hpp:10-13: matchingAlgorithm; the only value the reference has. */
 #define SFM_MATCH_TWO_SIDED 0
@@ -161,6 +162,21 @@ int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set,
                           const int32_t *pair_list, int n_pairs,
                           float threshold, float max_distance_px_squared, float ratio,
                           sfm_match_result **result_inout);
+/* Extension with no counterpart in the reference (its metrics are cosine and dot,
+ * match.hpp:18-46; pinned by this library's CPU restatement only): the structure
+ * of matchTwoSided (match.cpp:24-94) under the squared Euclidean distance, for
+ * descriptors that are not unit-norm (where the L2 order differs from the cosine
+ * order).  d^2(a, b) = (|a|^2 + |b|^2) - 2 a.b, each of the three an fp32 sum in
+ * index order, negative results clamped to 0.  A cell is admissible when
+ * d^2 < max_distance_squared and the keypoints lie inside the pixel gate; rows and
+ * columns keep their nearest admissible cell (the lowest index among equals);
+ * ratio > 0 adds Lowe's test: a row keeps its best at d1 only if every other
+ * column inside the gate has d1^2 < ratio^2 d2^2 (in double); then the mutual
+ * check, ascending row.  ratio = 0: no test; else ratio in (0, 1]. */
+int sfm_match_batch_l2(sfm_ctx *ctx, const sfm_imageset *set,
+                       const int32_t *pair_list, int n_pairs,
+                       float max_distance_squared, float max_distance_px_squared, float ratio,
+                       sfm_match_result **result_inout);
 int sfm_match_result_total(sfm_match_result *res, int64_t *total_matches_out);
 int sfm_match_result_offsets(sfm_match_result *res, int64_t *offsets_out /* n_pairs+1 */);
 int sfm_match_result_pairs(sfm_match_result *res, int32_t *pairs_out /* 2*total */);

@@ -49,6 +49,9 @@ def lib() -> C.CDLL:
     L.sfm_oracle_match_ratio.restype = C.c_int
     L.sfm_oracle_match_ratio.argtypes = [_f32p, _f64p, C.c_int, _f32p, _f64p, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_float, _i32p, _i32p, _i32p]
+    L.sfm_oracle_match_l2.restype = C.c_int
+    L.sfm_oracle_match_l2.argtypes = [_f32p, _f64p, C.c_int, _f32p, _f64p, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, C.c_float, _i32p, _i32p, _i32p]
     L.sfm_oracle_match_hamming.restype = C.c_int
     L.sfm_oracle_match_hamming.argtypes = [_u8p, _f64p, C.c_int, _u8p, _f64p, C.c_int, C.c_int, C.c_int, C.c_float,
                                            _i32p, _i32p, _i32p]
@@ -308,6 +311,28 @@ def match_hamming(descA, ptsA, descB, ptsB, max_distance=64, max_dist_sq=1e8):
     cnt = lib().sfm_oracle_match_hamming(pad(descA, (1, nbytes), np.uint8), pad(ptsA, (1, 2), np.float64), nA,
                                          pad(descB, (1, nbytes), np.uint8), pad(ptsB, (1, 2), np.float64), nB,
                                          nbytes, int(max_distance), np.float32(max_dist_sq), m1, m2, pairs.reshape(-1))
+    if cnt < 0:
+        raise MemoryError("oracle allocation failed")
+    return pairs[:cnt].copy(), m1[:nA].copy(), m2[:nB].copy()
+
+
+def match_l2(descA, ptsA, descB, ptsB, max_dist_sq_desc, max_dist_sq=1e8, ratio=0.0):
+    """Mutual nearest neighbours under the squared Euclidean distance (extension; no counterpart in the
+    reference).  Returns (pairs[k,2] int32, matches1[nA], matches2[nB])."""
+    ptsA = np.ascontiguousarray(ptsA, np.float64).reshape(-1, 2)
+    ptsB = np.ascontiguousarray(ptsB, np.float64).reshape(-1, 2)
+    nA, nB = len(ptsA), len(ptsB)
+    descA = np.ascontiguousarray(descA, np.float32).reshape(nA, -1) if nA else np.zeros((0, 128), np.float32)
+    descB = np.ascontiguousarray(descB, np.float32).reshape(nB, -1) if nB else np.zeros((0, descA.shape[1]), np.float32)
+    dim = descA.shape[1] if nA else descB.shape[1]
+    m1 = np.full(max(nA, 1), -1, np.int32)
+    m2 = np.full(max(nB, 1), -1, np.int32)
+    pairs = np.zeros((max(min(nA, nB), 1), 2), np.int32)
+    pad = lambda a, shape, dt: a if a.size else np.zeros(shape, dt)
+    cnt = lib().sfm_oracle_match_l2(pad(descA, (1, dim), np.float32), pad(ptsA, (1, 2), np.float64), nA,
+                                    pad(descB, (1, dim), np.float32), pad(ptsB, (1, 2), np.float64), nB, dim,
+                                    np.float32(max_dist_sq_desc), np.float32(max_dist_sq), np.float32(ratio), m1, m2,
+                                    pairs.reshape(-1))
     if cnt < 0:
         raise MemoryError("oracle allocation failed")
     return pairs[:cnt].copy(), m1[:nA].copy(), m2[:nB].copy()

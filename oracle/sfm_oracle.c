@@ -1416,3 +1416,100 @@ int sfm_oracle_match_hamming(const uint8_t *descA, const double *ptsA, int nA, c
     free(d2);
     return count;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Extension with no counterpart in the reference (PARITY UNPINNED by it; its metrics are cosine and
+ * dot, match.hpp:18-46): the structure of matchTwoSided (match.cpp:24-94) under the squared Euclidean
+ * distance in its expanded form.  d^2 = (|a|^2 + |b|^2) - 2 a.b with the three sums accumulated in one
+ * loop in index order (as cosineSimilarity accumulates them, match.hpp:38-43), negative values clamped
+ * to 0.  A cell is admissible when d^2 < maxDistanceSquared and the keypoints are inside the pixel gate;
+ * columns and rows take their nearest admissible cell, the first of equals; ratio > 0: a row keeps its
+ * best at d1 only if every other column inside the gate has d1^2 < ratio^2 d2^2 (double); mutual pairs
+ * in ascending row order (match.cpp:84-91).
+ * --------------------------------------------------------------------------------------------- */
+static float squared_distance(const float *a, const float *b, size_t n)
+{
+    float dot = 0.0f, normA = 0.0f, normB = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        dot += a[i] * b[i];
+        normA += a[i] * a[i];
+        normB += b[i] * b[i];
+    }
+    float d2 = (normA + normB) - 2.0f * dot;
+    return d2 < 0.0f ? 0.0f : d2;
+}
+
+int sfm_oracle_match_l2(const float *descA, const double *ptsA, int nA, const float *descB, const double *ptsB, int nB,
+                        int dim, float maxDistanceSquared, float maxDistancePxSquared, float ratio, int *matches1_out,
+                        int *matches2_out, int *pairs_out)
+{
+    int *m1 = (int *)malloc((size_t)(nA > 0 ? nA : 1) * sizeof(int));
+    int *m2 = (int *)malloc((size_t)(nB > 0 ? nB : 1) * sizeof(int));
+    float *d1 = (float *)malloc((size_t)(nA > 0 ? nA : 1) * sizeof(float));
+    if (!m1 || !m2 || !d1) {
+        free(m1);
+        free(m2);
+        free(d1);
+        return -1;
+    }
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < nB; j++) {
+        int best = -1;
+        float bestD = INFINITY;
+        for (int i = 0; i < nA; i++) {
+            const float d = squared_distance(descA + (size_t)i * dim, descB + (size_t)j * dim, (size_t)dim);
+            const double dx = ptsA[2 * i] - ptsB[2 * j], dy = ptsA[2 * i + 1] - ptsB[2 * j + 1];
+            if (d < maxDistanceSquared && dx * dx + dy * dy < maxDistancePxSquared && d < bestD) {
+                bestD = d;
+                best = i;
+            }
+        }
+        m2[j] = best;
+    }
+    const double r2 = (double)ratio * (double)ratio;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < nA; i++) {
+        int best = -1;
+        float bestD = INFINITY;
+        for (int j = 0; j < nB; j++) {
+            const float d = squared_distance(descA + (size_t)i * dim, descB + (size_t)j * dim, (size_t)dim);
+            const double dx = ptsA[2 * i] - ptsB[2 * j], dy = ptsA[2 * i + 1] - ptsB[2 * j + 1];
+            if (d < maxDistanceSquared && dx * dx + dy * dy < maxDistancePxSquared && d < bestD) {
+                bestD = d;
+                best = j;
+            }
+        }
+        m1[i] = best;
+        d1[i] = bestD;
+        if (best >= 0 && ratio > 0.0f) {
+            for (int j = 0; j < nB; j++) {
+                if (j == best) continue;
+                const double dx = ptsA[2 * i] - ptsB[2 * j], dy = ptsA[2 * i + 1] - ptsB[2 * j + 1];
+                if (!(dx * dx + dy * dy < maxDistancePxSquared)) continue;
+                const float d = squared_distance(descA + (size_t)i * dim, descB + (size_t)j * dim, (size_t)dim);
+                if (!(d == d)) continue;
+                if (!((double)bestD < r2 * (double)d)) {
+                    m1[i] = -1;
+                    break;
+                }
+            }
+        }
+    }
+    int count = 0;
+    for (int i = 0; i < nA; i++) {
+        const int j = m1[i];
+        if (j != -1 && m2[j] == i) {
+            if (pairs_out) {
+                pairs_out[2 * count] = i;
+                pairs_out[2 * count + 1] = j;
+            }
+            count++;
+        }
+    }
+    if (matches1_out) memcpy(matches1_out, m1, (size_t)nA * sizeof(int));
+    if (matches2_out) memcpy(matches2_out, m2, (size_t)nB * sizeof(int));
+    free(m1);
+    free(m2);
+    free(d1);
+    return count;
+}

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP = range(7)
-METRIC_COSINE, METRIC_DOT = 0, 1
+METRIC_COSINE, METRIC_DOT, METRIC_L2 = 0, 1, 2
 MATCH_TWO_SIDED = 0
 LOSS_REPROJECTION, LOSS_SAMPSON = 0, 1
 
@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
-    "sfm_match_batch_ratio", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
+    "sfm_match_batch_ratio", "sfm_match_batch_l2", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
     "sfm_shard_count", "sfm_shard_indices", "sfm_shard_layout", "sfm_comm_unique_id", "sfm_comm_create",
     "sfm_comm_create_local", "sfm_comm_rank", "sfm_comm_destroy", "sfm_match_gather", "sfm_match_gather_local",
     "sfm_match_batch_multi", "sfm_gathered_wait", "sfm_gathered_total", "sfm_gathered_layout", "sfm_gathered_pairs", "sfm_gathered_device",
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
     L.sfm_imageset_device_bytes.restype = i64
     L.sfm_match_batch.argtypes = [vp, vp, vp, i32, i32, f32, f32, P(vp)]
     L.sfm_match_batch_ratio.argtypes = [vp, vp, vp, i32, f32, f32, f32, P(vp)]
+    if hasattr(L, "sfm_match_batch_l2"):
+        L.sfm_match_batch_l2.argtypes = [vp, vp, vp, i32, f32, f32, f32, P(vp)]
     L.sfm_binset_create.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
     L.sfm_binset_destroy.argtypes = [vp]
     L.sfm_binset_destroy.restype = None
@@ -548,7 +550,10 @@ class ImageSet:
         """ratio: Lowe's second-best test on top of the reference's matcher (sfm_match_batch_ratio)."""
         pl = np.ascontiguousarray(pair_list, np.int32).reshape(-1, 2)
         res = result if result is not None else MatchResult(self.ctx)
-        if ratio is not None:
+        if metric == METRIC_L2:  # threshold = largest admissible squared descriptor distance
+            self.ctx.check(lib().sfm_match_batch_l2(self.ctx._h, self._h, _ptr(pl), len(pl), threshold, max_dist_sq,
+                                                    float(ratio or 0.0), C.byref(res._h)))
+        elif ratio is not None:
             if metric != METRIC_COSINE:
                 raise SfmError(ERR_UNSUPPORTED, "the second-best ratio test is defined for the cosine metric only")
             self.ctx.check(lib().sfm_match_batch_ratio(self.ctx._h, self._h, _ptr(pl), len(pl), threshold,

@@ -50,8 +50,11 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 // One thread per descriptor: normA += a[i]*a[i] in index order, no contraction
 // (match.hpp:38-43), then sqrtf.
+// normRange[2 * image] = 0x7FFFFFFF - bits of the smallest norm, [2 * image + 1] = bits of the largest (norms
+// inside the safe range only; both start at 0 and grow under atomicMax).
 __global__ void ingest_norm_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
-                                   int dim, float *__restrict__ norms, int *__restrict__ imageFlags)
+                                   int dim, float *__restrict__ norms, float *__restrict__ norms2, int *__restrict__ imageFlags,
+                                   int *__restrict__ normRange)
 {
     const ImageRec im = images[blockIdx.y];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,7 +70,12 @@ __global__ void ingest_norm_kernel(const float *__restrict__ desc32, const Image
     // under -fhip-fp32-correctly-rounded-divide-sqrt, like std::sqrt on the host (match.hpp:45)
     const float s = sqrtf(normA);
     norms[im.row32 + r] = s;
+    norms2[im.row32 + r] = normA; // the squared norm as the reference's loop accumulates it (L2 mode)
     const bool inRange = (s >= 1e-12f) && (s <= 1e12f);
+    if (inRange) {
+        atomicMax(&normRange[2 * blockIdx.y], 0x7FFFFFFF - __float_as_int(s));
+        atomicMax(&normRange[2 * blockIdx.y + 1], __float_as_int(s));
+    }
     int f = bytes ? 0 : IMG_NOT_U8;
     if (!inRange) {
         f |= IMG_WILD_DOT;
@@ -179,6 +187,21 @@ __global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRe
 // The part of a cell's evaluation after the dot product: metric, threshold, pixel gate, arg-max keys.
 __device__ __forceinline__ void fold_dot(const MatchArgs &g, const PairRec &pr, int i, int j, float dot)
 {
+    if (g.metric == SFM_METRIC_L2) {
+        // Extension (no counterpart in the reference): squared Euclidean distance in the expanded form
+        // |a|^2 + |b|^2 - 2 a.b, every term an fp32 sum in index order; a cell is admissible below the
+        // caller's maximum; rows and columns keep their nearest admissible cell, the lowest index among equals.
+        float d2 = __fsub_rn(__fadd_rn(g.norms2[pr.rowA32 + i], g.norms2[pr.rowB32 + j]), __fmul_rn(2.0f, dot));
+        if (d2 < 0.0f) d2 = 0.0f;
+        if (!(d2 < g.threshold)) return;
+        const double2 qa = g.pts[pr.rowA32 + i], qb = g.pts[pr.rowB32 + j];
+        const double ex = __dsub_rn(qa.x, qb.x), ey = __dsub_rn(qa.y, qb.y);
+        if (!(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)) < (double)g.maxDistSq)) return;
+        const u64 key = (u64)(~__float_as_uint(d2)) << 32; // non-negative floats order like their bits: smaller distance, larger key
+        atomicMax(&g.best[pr.bestRow + i], key | (u64)(0xFFFFFFFFu - (unsigned)j));
+        atomicMax(&g.best[pr.bestCol + j], key | (u64)(0xFFFFFFFFu - (unsigned)i));
+        return;
+    }
     float sim = dot; // match.hpp:18-27
     if (g.metric == SFM_METRIC_COSINE) // match.hpp:45
         sim = __fdiv_rn(dot, __fmul_rn(g.norms[pr.rowA32 + i], g.norms[pr.rowB32 + j]));
@@ -224,6 +247,17 @@ __device__ __forceinline__ void ratio_fold(const MatchArgs &g, const PairRec &pr
     const u64 key = g.best[pr.bestRow + i];
     if (key == 0) return;
     if ((int)(0xFFFFFFFFu - (unsigned)key) == j) return;
+    if (g.metric == SFM_METRIC_L2) { // d1^2 < ratio^2 d2^2 against every other column inside the pixel gate
+        float d2 = __fsub_rn(__fadd_rn(g.norms2[pr.rowA32 + i], g.norms2[pr.rowB32 + j]), __fmul_rn(2.0f, dot));
+        if (d2 < 0.0f) d2 = 0.0f;
+        if (!(d2 == d2)) return;
+        const double2 qa = g.pts[pr.rowA32 + i], qb = g.pts[pr.rowB32 + j];
+        const double ex = __dsub_rn(qa.x, qb.x), ey = __dsub_rn(qa.y, qb.y);
+        if (!(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)) < (double)g.maxDistSq)) return;
+        const double d1 = (double)__uint_as_float(~(unsigned)(key >> 32));
+        if (!(d1 < __dmul_rn(g.ratioSq, (double)d2))) g.kill[pr.bestRow + i] = 1;
+        return;
+    }
     const float sim = __fdiv_rn(dot, __fmul_rn(g.norms[pr.rowA32 + i], g.norms[pr.rowB32 + j]));
     if (!(sim == sim)) return;
     const double2 pa = g.pts[pr.rowA32 + i], pb = g.pts[pr.rowB32 + j];
@@ -646,7 +680,9 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
         if (wq.n > wq.cap) {
-            const int flag = GENERAL ? 2 : (I8 ? 3 : 1);
+            // (the filtered passes rank cells by cosine, which is not the L2 order when norms differ: an L2 pair
+            // whose fp16 strict list overflows is scored cell by cell)
+            const int flag = GENERAL ? 2 : (I8 ? 3 : (g.metric == SFM_METRIC_L2 ? 2 : 1));
             g.pairOvf[pr.chunkLocal] = flag;
             atomicAdd(&g.flagCount[flag], 1); // "some pair carries this flag", for the passes that walk the list
         }
@@ -956,6 +992,7 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
     s->desc8u.release();
     s->imageStats.release();
     s->norms.release();
+    s->norms2.release();
     if (s->owns_pts) s->pts.release();
     s->imageRecs.release();
     s->imageFlags.release();
@@ -1073,9 +1110,10 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     }
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
     SET_HIP(s->desc8.reserve((size_t)r16 * 128));
-    SET_HIP(s->imageStats.reserve((size_t)(n_images ? n_images : 1) * 2 * sizeof(int)));
+    SET_HIP(s->imageStats.reserve((size_t)(n_images ? n_images : 1) * 4 * sizeof(int))); // [n][2] int8 statistics, then [n][2] norm range
+    SET_HIP(s->norms2.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(hipMemsetAsync(s->desc8.p, 0, (size_t)r16 * 128, ctx->stream));
-    SET_HIP(hipMemsetAsync(s->imageStats.p, 0, (size_t)(n_images ? n_images : 1) * 2 * sizeof(int), ctx->stream));
+    SET_HIP(hipMemsetAsync(s->imageStats.p, 0, (size_t)(n_images ? n_images : 1) * 4 * sizeof(int), ctx->stream));
     SET_HIP(s->norms.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(s->imageRecs.reserve((size_t)(n_images ? n_images : 1) * sizeof(ImageRec)));
     SET_HIP(s->imageFlags.reserve((size_t)(n_images ? n_images : 1) * sizeof(int)));
@@ -1087,7 +1125,8 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
                                hipMemcpyHostToDevice, ctx->stream));
         dim3 g1((maxN + 255) / 256, n_images);
         hipLaunchKernelGGL(ingest_norm_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
-                           s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->imageFlags.as<int>());
+                           s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->norms2.as<float>(), s->imageFlags.as<int>(),
+                           s->imageStats.as<int>() + 2 * (size_t)n_images);
         dim3 g2(((int64_t)maxN * 16 + 255) / 256, n_images);
         hipLaunchKernelGGL(ingest_f16_kernel, g2, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
                            s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->desc16.as<_Float16>());
@@ -1098,18 +1137,23 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         // int8 table: per-image scale from the largest unit-normalised element
         hipLaunchKernelGGL(ingest_stats_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
                            s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>());
-        std::vector<int> stats((size_t)n_images * 2);
+        std::vector<int> stats((size_t)n_images * 4);
         SET_HIP(hipMemcpyAsync(stats.data(), s->imageStats.p, stats.size() * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
         SET_HIP(hipStreamSynchronize(ctx->stream));
         s->scale8.assign(n_images, 1.0f);
         s->l1max.assign(n_images, 0.0f);
+        s->normMin.assign(n_images, 0.0f);
+        s->normMax.assign(n_images, 0.0f);
         for (int i = 0; i < n_images; i++) {
             float mx, l1;
             memcpy(&mx, &stats[2 * i], 4);
             memcpy(&l1, &stats[2 * i + 1], 4);
             s->scale8[i] = (mx > 0.0f) ? 127.0f / mx : 1.0f;
             s->l1max[i] = l1;
+            const int lo = 0x7FFFFFFF - stats[2 * (size_t)n_images + 2 * i], hi = stats[2 * (size_t)n_images + 2 * i + 1];
+            memcpy(&s->normMin[i], &lo, 4); // NaN pattern when the image has no in-range descriptor
+            memcpy(&s->normMax[i], &hi, 4);
             memcpy(&s->images[i].pad, &s->scale8[i], 4);
         }
         SET_HIP(hipMemcpyAsync(s->imageRecs.p, s->images.data(), (size_t)n_images * sizeof(ImageRec),
@@ -1131,6 +1175,8 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     if (s->scale8.empty()) {
         s->scale8.assign(n_images, 1.0f);
         s->l1max.assign(n_images, 0.0f);
+        s->normMin.assign(n_images, 0.0f);
+        s->normMax.assign(n_images, 0.0f);
     }
     SET_HIP(hipStreamSynchronize(ctx->stream));
 #undef SET_HIP
@@ -1184,11 +1230,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     if (!ctx || !set || !result_inout) return SFM_ERR_INVALID_ARG;
     if (ratio != 0.0f && !(ratio > 0.0f && ratio <= 1.0f))
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1], was %g", (double)ratio);
-    if (ratio != 0.0f && metric != SFM_METRIC_COSINE)
-        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "match: the second-best ratio test is defined for the cosine metric only");
+    if (ratio != 0.0f && metric == SFM_METRIC_DOT)
+        SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "match: the second-best ratio test is not defined for the dot metric");
     if (set->ctx != ctx) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: image set belongs to another context");
     if (n_pairs < 0 || (n_pairs > 0 && !pair_list)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: bad pair list");
-    if (metric != SFM_METRIC_COSINE && metric != SFM_METRIC_DOT)
+    if (metric != SFM_METRIC_COSINE && metric != SFM_METRIC_DOT && metric != SFM_METRIC_L2)
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: unknown similarity metric %d", metric);
     SFM_HIP(ctx, hipSetDevice(ctx->device));
 
@@ -1280,15 +1326,32 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             bestOff += (int64_t)A.n + B.n;
             r.chunkLocal = p - c0;
             const int wildMask = (metric == SFM_METRIC_COSINE) ? IMG_WILD_COS : IMG_WILD_DOT;
-            const bool wild = ((set->flags[ia] | set->flags[ib]) & wildMask) != 0;
+            bool wild = ((set->flags[ia] | set->flags[ib]) & wildMask) != 0;
             float thrp = threshold > 0.0f ? threshold : 0.0f;
+            bool l2Open = false; // L2: no cosine bound holds for this pair
+            if (metric == SFM_METRIC_L2) {
+                // d^2 < T  =>  a.b > (|a|^2 + |b|^2 - T) / 2  =>  cos > 1 - T / (2 |a| |b|)   (|a|^2 + |b|^2 >= 2 |a| |b|)
+                //          >=  1 - T / (2 minA minB).  The fp32 evaluation of d^2 is within 1e-4 (maxA^2 + maxB^2) of the
+                // exact one; the ratio mode collects down to T / ratio^2 (a rival at d2 undoes a best at d1 < T
+                // only if d2 <= d1 / ratio^2).
+                const double lo = (double)set->normMin[ia] * (double)set->normMin[ib];
+                const double hi2 = (double)set->normMax[ia] * set->normMax[ia] + (double)set->normMax[ib] * set->normMax[ib];
+                double T = (double)threshold;
+                if (ratio > 0.0f) T = T / ((double)ratio * ratio);
+                const double c = 1.0 - (T + 1e-4 * hi2) / (2.0 * lo) - 1e-6;
+                if (!(lo > 0.0) || !(c == c) || c < -1.5) l2Open = true;
+                thrp = l2Open ? 0.0f : (float)std::max(c, -1.5);
+            }
             // Ratio mode: a row whose best has similarity s1 > threshold is undone by any column at or
             // above 1 - (1 - s1) / ratio^2, which is more than 1 - (1 - threshold) / ratio^2: the bound
             // pass collects down to there, and the exact pass still applies the threshold itself.
-            if (ratio > 0.0f && threshold == threshold)
+            if (metric != SFM_METRIC_L2 && ratio > 0.0f && threshold == threshold)
                 thrp = std::max(-2.0f, (float)(1.0 - (1.0 - (double)thrp) / ((double)ratio * ratio) - 1e-6));
+            wild = wild || l2Open;
             if (wild)
                 r.thr_m = -INFINITY;
+            else if (metric == SFM_METRIC_L2)
+                r.thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN; // thrp may be negative here
             else if (metric == SFM_METRIC_COSINE)
                 r.thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN;
             else
@@ -1302,7 +1365,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             const double t = ((double)thrp - 1e-4) * sA * sB - err;
             if (threshold != threshold)
                 r.thr_i = INT_MAX;
-            else if (wild || metric != SFM_METRIC_COSINE || !(t > -1e9))
+            else if (wild || metric == SFM_METRIC_DOT || !(t > -1e9))
                 r.thr_i = -(1 << 30);
             else
                 r.thr_i = (int32_t)std::floor(std::min(t, 2.0e9));
@@ -1371,6 +1434,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.desc8u = set->u8_exact ? set->desc8u.as<unsigned char>() : nullptr;
     g.desc32 = set->desc32.as<float>();
     g.norms = set->norms.as<float>();
+    g.norms2 = set->norms2.as<float>();
     g.pts = set->pts.as<double2>();
     g.maxQueues = maxQueues;
     g.blockRows = BLOCK_ROWS;
@@ -1426,7 +1490,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         const int nblk = chunkWorkCount[0][ci];
         const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
         if (nblk > 0) {
-            const bool cosine = metric == SFM_METRIC_COSINE;
+            const bool cosine = metric != SFM_METRIC_DOT; // the L2 mode runs the cosine bound passes with its own per-pair bound
             if (cosine) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
@@ -1535,6 +1599,17 @@ extern "C" int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set, cons
     if (ctx && !(ratio > 0.0f && ratio <= 1.0f))
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1], was %g", (double)ratio);
     const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_COSINE, threshold, max_distance_px_squared,
+                                    result_inout, false, ratio);
+    return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
+}
+
+extern "C" int sfm_match_batch_l2(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
+                                  float max_distance_squared, float max_distance_px_squared, float ratio,
+                                  sfm_match_result **result_inout)
+{
+    if (ctx && ratio != 0.0f && !(ratio > 0.0f && ratio <= 1.0f))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1] (0 = no test), was %g", (double)ratio);
+    const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_L2, max_distance_squared, max_distance_px_squared,
                                     result_inout, false, ratio);
     return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
 }

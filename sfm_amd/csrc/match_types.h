@@ -30,6 +30,7 @@ struct MatchArgs {
     const unsigned char *desc8u; // byte copy of desc32 (dim 128, rows as desc32) when every element is an integer in [0, 255], else null
     const float *desc32;
     const float *norms;
+    const float *norms2;  // squared norms, fp32 sums in index order (L2 mode)
     const double2 *pts;
     const PairRec *pairs; // chunk base
     const int2 *work;     // (pair in chunk, row block), -1 = no work
@@ -66,9 +67,10 @@ struct sfm_imageset {
     std::vector<ImageRec> images;
     std::vector<int> flags;
     int64_t rows32 = 0, rows16 = 0;
-    DevBuf desc32, desc16, desc8, desc8u, norms, pts, imageRecs, imageFlags, imageStats;
+    DevBuf desc32, desc16, desc8, desc8u, norms, norms2, pts, imageRecs, imageFlags, imageStats;
     std::vector<float> scale8; // per image: int8 value = round(unit-normalised element * scale8)
     std::vector<float> l1max;  // per image: largest L1 norm of a unit-normalised descriptor
+    std::vector<float> normMin, normMax; // per image: smallest / largest descriptor norm inside the safe range
     bool owns_desc32 = true, owns_pts = true;
     bool u8_exact = false;     // desc8u holds a byte copy of desc32 (every element an integer in [0, 255], dim 128)
 };
