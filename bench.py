@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--ransac-distinct", type=int, default=500,
                     help="correspondence sets generated on the host; the batch repeats them (separate copies in HBM, "
                          "every pair with a sample table of its own)")
+    ap.add_argument("--rehearse-gather", action="store_true",
+                    help="with one rank (launched through torch.distributed.run): run the N > 1 code path anyway, "
+                         "process group, communicator and gather included")
     ap.add_argument("--no-regimes", action="store_true", help="skip the matcher's other regimes and the extra RANSAC rows")
     ap.add_argument("--ransac-corr", type=int, default=20000)
     ap.add_argument("--ransac-hyps", type=int, default=4096)
@@ -81,6 +84,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    # Standard output carries the one JSON line and nothing else: libraries that write to file descriptor 1
+    # (RCCL prints a version banner there when a communicator is created) go to standard error instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from sfm_amd import capi, shard, synth
 
@@ -88,7 +97,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP library has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.rehearse_gather  # the N > 1 code path
+    if multi:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     ctx = capi.Context(local_rank)
@@ -132,9 +142,9 @@ def main():
     gathers = [None, None]
     gathered = None
     res = None
-    gather_mode = args.gather if world > 1 else "none"
+    gather_mode = args.gather if multi else "none"
     comm = None
-    if world > 1 and gather_mode == "library":
+    if multi and gather_mode == "library":
         try:
             comm = shard.library_comm(ctx, rank, world)
         except capi.SfmError as e:  # an error, not a hang: the torch.distributed stand-by takes over on every rank
@@ -173,16 +183,16 @@ def main():
         prev = None
         for k in range(n_steps):
             res = launch(k)
-            if world > 1 and prev is not None:
+            if multi and prev is not None:
                 gather(prev, k - 1)
             ctx.synchronize()
-            if world > 1 and comm is None:
+            if multi and comm is None:
                 torch.cuda.synchronize()  # the gather reads prev's buffers, which step k + 1 overwrites
                 res.total()               # cached: gather() must not wait on the library's stream later
             a, b = ctx.last_kernel_ms(0)
             ms, nl = ms + a, nl + b
             prev = res
-        if world > 1 and prev is not None:
+        if multi and prev is not None:
             gather(prev, n_steps - 1)
             for g in gathers:
                 if g is not None:
@@ -196,7 +206,7 @@ def main():
     kernel_ms, kernel_launches = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -204,7 +214,7 @@ def main():
     total_matches = res.total()
     cand, ovf = res.stats()
     gathered_total = None
-    if rank == 0 and world > 1 and gathered is not None:
+    if rank == 0 and multi and gathered is not None:
         gathered_total = int(gathered.total()) if comm is not None else int(gathered[2].shape[0])
     value = total_pairs * args.steps / elapsed
     flops_per_pair = 2.0 * args.features * args.features * 128
@@ -270,7 +280,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, desc, pts, out.get("ransac"), pipe_inputs)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        line = (json.dumps(out) + "\n").encode()
+        while line:
+            line = line[os.write(json_fd, line):]
     if comm is not None:
         for g in gathers:
             if g is not None:

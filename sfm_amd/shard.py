@@ -33,9 +33,11 @@ def library_comm(ctx, rank: int, world: int):
     """The library's communicator for this rank, its id handed round through torch.distributed (any
     initialised process group will do; world 1 needs none)."""
     from . import capi
-    if world <= 1:
-        return capi.Comm.create(ctx, 0, 1, capi.Comm.unique_id())
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        if world > 1:
+            raise RuntimeError("library_comm: more than one rank needs an initialised torch.distributed process group")
+        return capi.Comm.create(ctx, 0, 1, capi.Comm.unique_id())
     box = [capi.Comm.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     return capi.Comm.create(ctx, rank, world, box[0])
