@@ -106,6 +106,8 @@ def main():
     ctx.set_option("sim_variant", sim_variant)
     if "SFM_MATCH_OVERLAP" in os.environ:  # A/B switch of the matcher's two-stream chunk overlap
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
+    if "SFM_MATCH_COL_SPLIT" in os.environ:  # A/B switch: column parts per row block of small matcher launches
+        ctx.set_option("match_col_split", int(os.environ["SFM_MATCH_COL_SPLIT"]))
     if args.first_slice > 0:
         ctx.set_option("hyps_per_launch", args.first_slice)
     if args.pairs_per_launch > 0:
@@ -445,20 +447,28 @@ def bench_pipeline(ctx, args):
     cx, cy = corr.fetch()
     coff = corr.offsets()
     x0, y0 = cx[coff[0]:coff[1]], cy[coff[0]:coff[1]]
-    calls = 30  # steady state: the first dozen calls of a process run at half speed (clocks, runtime pools)
-    for _ in range(10):
-        ctx.match_pair(desc[f0], pts[f0], desc[f1], pts[f1], threshold=0.95, max_dist_sq=100.0 * 100.0)
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        ctx.match_pair(desc[f0], pts[f0], desc[f1], pts[f1], threshold=0.95, max_dist_sq=100.0 * 100.0)
-    match_call_ms = (time.perf_counter() - t0) / calls * 1e3
+    def per_call_ms(fn, calls=30, rounds=3):
+        """Steady state: the first dozen calls of a process run at half speed (clocks, runtime pools), and a box that
+        has just run a long kernel may take a round to settle: ten calls untimed, then the best of three rounds."""
+        for _ in range(10):
+            fn()
+        best_ms, last = float("inf"), None
+        for _ in range(rounds):
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                last = fn()
+            best_ms = min(best_ms, (time.perf_counter() - t0) / calls * 1e3)
+        return best_ms, last
+
+    dA, pA, dB, pB = desc[f0], pts[f0], desc[f1], pts[f1]
+    match_call_ms, _ = per_call_ms(lambda: ctx.match_pair(dA, pA, dB, pB, threshold=0.95, max_dist_sq=100.0 * 100.0))
+    # the same tables in page-locked memory (sfm_host_alloc), where an adaptor that packs Keypoints can keep them
+    qA, rA, qB, rB = (ctx.pinned_like(a) for a in (dA, pA, dB, pB))
+    match_pinned_ms, _ = per_call_ms(lambda: ctx.match_pair(qA, rA, qB, rB, threshold=0.95, max_dist_sq=100.0 * 100.0))
+    del qA, rA, qB, rB
     ctx.set_option("ransac_seed", 20261111)
-    for _ in range(10):
-        ctx.ransac_pair(x0, y0, K, H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        rr = ctx.ransac_pair(x0, y0, K, H, max_sq_err=1.0, success_prob=0.999, adaptive=True, per_row=False)
-    ransac_call_ms = (time.perf_counter() - t0) / calls * 1e3
+    ransac_call_ms, rr = per_call_ms(lambda: ctx.ransac_pair(x0, y0, K, H, max_sq_err=1.0, success_prob=0.999, adaptive=True,
+                                                           per_row=False))
     ctx.set_option("ransac_seed", 0)
     out = {
         "workload": f"{frames} synthetic frames x {feats} features, {frames - 1} consecutive pairs, {H} hypotheses per pair",
@@ -470,8 +480,10 @@ def bench_pipeline(ctx, args):
         "tracks": int(n_tracks), "points_averaged": int((chain["counts"] > 1).sum()),
         "one_pair_per_call": {
             "what": "the reference's call pattern: sfm_match_pair / sfm_ransac_pair once per frame pair, host buffers in "
-                    "(pageable), lists out; upload, ingest and download inside the time",
-            "match_pair_ms": round(match_call_ms, 3), "features": int(counts[0]),
+                    "(pageable unless said otherwise), lists out; upload, ingest and download inside the time; mean of 30 "
+                    "calls, best of three rounds after ten untimed calls",
+            "match_pair_ms": round(match_call_ms, 3), "match_pair_ms_tables_in_page_locked_memory": round(match_pinned_ms, 3),
+            "features": int(counts[0]),
             "ransac_pair_ms": round(ransac_call_ms, 3), "correspondences": int(len(x0)), "hypotheses": H,
             "ransac_iterations": int(rr["iterations"]), "ransac_inliers": int(len(rr["inliers"])),
         },

@@ -84,10 +84,23 @@ const char *sfm_version(void);
  * bound passes on a second stream of the context while the next chunk's bound
  * passes start, default; 0 = everything on one stream; results are identical;
  * either way the call's work is ordered before whatever follows it on the
- * context).
+ * context), "match_col_split" (0 = a matcher launch too small to fill the
+ * device cuts every row block's columns into 2, 4, 8 or 16 parts, one block
+ * each, default; 1, 2, 4, 8, 16 = that many parts always; results are
+ * identical).
  * Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */
 int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);
+
+/* Page-locked host memory.  No counterpart in the reference: the adaptor that
+ * packs std::vector<Keypoint> into tables (match.hpp:49-53) owns those tables
+ * and may as well keep them here; sfm_match_pair and sfm_ransac_pair then
+ * upload at the link's rate (about twice the rate from pageable memory, which
+ * the runtime has to pin piece by piece).  Any host pointer is accepted by
+ * every entry point either way.  sfm_host_free may be called after the
+ * context is gone. */
+int sfm_host_alloc(sfm_ctx *ctx, size_t bytes, void **ptr_out);
+void sfm_host_free(void *ptr);
 
 /* Device time, in milliseconds, that the dominant kernel of the last batch
  * call spent (sum over its launches, measured with HIP events on the

@@ -26,7 +26,7 @@ _STATUS_NAMES = {1: "invalid argument", 2: "no gfx950 device", 3: "out of memory
 # Every symbol include/sfm_amd.h declares.
 EXPORTED_SYMBOLS = [
     "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_synchronize", "sfm_last_error", "sfm_version",
-    "sfm_ctx_set_option", "sfm_ctx_last_kernel_ms",
+    "sfm_ctx_set_option", "sfm_ctx_last_kernel_ms", "sfm_host_alloc", "sfm_host_free",
     "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_u8", "sfm_imageset_create_device", "sfm_imageset_destroy",
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
@@ -70,6 +70,9 @@ def lib() -> C.CDLL:
     L.sfm_ctx_create.argtypes = [i32, P(vp)]
     L.sfm_ctx_destroy.argtypes = [vp]
     L.sfm_ctx_destroy.restype = None
+    L.sfm_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.sfm_host_free.argtypes = [vp]
+    L.sfm_host_free.restype = None
     L.sfm_ctx_synchronize.argtypes = [vp]
     L.sfm_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
     L.sfm_ctx_last_kernel_ms.argtypes = [vp, i32, P(f64), P(i32)]
@@ -309,6 +312,21 @@ def _chain_result(out, S, n_tracks):
                 counts=out[2][:n_tracks], scale=out[3][:S])
 
 
+class _PinnedBlock:
+    """Page-locked host bytes from sfm_host_alloc, exposed through the array interface; numpy arrays made from
+    it keep it alive, and it returns the memory when the last of them has gone."""
+
+    def __init__(self, addr, nbytes):
+        self.addr = addr
+        self.__array_interface__ = dict(shape=(max(nbytes, 1),), typestr="|u1", data=(addr, False), version=3)
+
+    def __del__(self):
+        try:
+            lib().sfm_host_free(self.addr)
+        except Exception:
+            pass
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -401,6 +419,16 @@ class Context:
 
     def imageset(self, counts, desc, pts, dim=None):
         return ImageSet(self, counts, desc, pts, dim)
+
+    def pinned_like(self, array):
+        """A copy of `array` in page-locked host memory (sfm_host_alloc); freed with the array's last view."""
+        array = np.ascontiguousarray(array)
+        p = C.c_void_p()
+        self.check(lib().sfm_host_alloc(self._h, array.nbytes, C.byref(p)))
+        block = _PinnedBlock(p.value, array.nbytes)
+        out = np.asarray(block)[:array.nbytes].view(array.dtype).reshape(array.shape)
+        out[...] = array
+        return out
 
     # ---- RANSAC ---------------------------------------------------------------------------
     def ransac_pair(self, x, y, K, samples, max_sq_err=10.0, success_prob=0.99, adaptive=True, min_n=8,

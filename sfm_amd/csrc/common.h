@@ -27,6 +27,7 @@ struct sfm_ctx {
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
     int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
+    int match_col_split = 0;         // column parts per row block in the matcher's strict passes; 0 = chosen per call from the launch size
     int match_overlap = 1;           // 0: the matcher's chunks run one after the other on `stream` only
     // Second stream of the batch matcher (what follows a chunk's bound passes), and the events that order the
     // two: ev[0..2] a chunk's bound passes are done, ev[3..5] its buffer set is clear again (by set), ev[6]

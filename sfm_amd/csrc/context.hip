@@ -109,6 +109,10 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->hamming_mfma = value != 0;
     } else if (!strcmp(key, "match_overlap")) {
         ctx->match_overlap = value != 0;
+    } else if (!strcmp(key, "match_col_split")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match_col_split must be 0 (chosen per call), 1, 2, 4, 8 or 16");
+        ctx->match_col_split = (int)value;
     } else if (!strcmp(key, "ransac_split")) {
         ctx->ransac_split = value != 0;
     } else if (!strcmp(key, "ransac_filter")) {
@@ -161,4 +165,24 @@ extern "C" int sfm_ctx_last_kernel_ms(sfm_ctx *ctx, int which, double *ms_out, i
     if (ms_out) *ms_out = total;
     if (launches_out) *launches_out = (int)ctx->span_used[which];
     return SFM_OK;
+}
+
+// Page-locked host memory for the caller's tables: the device reads it directly, so sfm_match_pair and
+// sfm_ransac_pair upload from it at the link's rate (the runtime pins pageable memory piece by piece, at
+// about half that rate).
+extern "C" int sfm_host_alloc(sfm_ctx *ctx, size_t bytes, void **ptr_out)
+{
+    if (!ctx || !ptr_out) return SFM_ERR_INVALID_ARG;
+    *ptr_out = nullptr;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) SFM_FAIL(ctx, SFM_ERR_OOM, "host_alloc: %zu bytes of page-locked memory: %s", bytes, hipGetErrorString(e));
+    *ptr_out = p;
+    return SFM_OK;
+}
+
+extern "C" void sfm_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
 }

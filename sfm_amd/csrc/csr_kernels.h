@@ -11,7 +11,10 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // mutual check + ordered compaction (match.cpp:84-91)
 // ---------------------------------------------------------------------------------------
-// One block per pair.  WRITE = false counts, WRITE = true writes (i, j) at offsets[p].
+// One block per pair.  WRITE = false counts, WRITE = true writes (i, j) at offsets[p].  A thread has four rows
+// in flight at a time (the row key leads to the column key: two dependent loads per row).
+// offsetsOut / totalOut (WRITE only, either may be null): a launch over a single pair needs no counting pass and
+// no scan; it writes offsetsOut[p + 1] = offsets[p] + count and totalOut[0] = count itself.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__restrict__ pairs,
                                                            const u64 *__restrict__ best,
@@ -19,48 +22,66 @@ __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__rest
                                                            const int64_t *__restrict__ offsets,
                                                            int2 *__restrict__ out,
                                                            int32_t *__restrict__ m1out,
-                                                           int32_t *__restrict__ m2out)
+                                                           int32_t *__restrict__ m2out,
+                                                           int64_t *__restrict__ offsetsOut,
+                                                           int64_t *__restrict__ totalOut)
 {
-    __shared__ int waveCnt[4];
+    constexpr int U = 4;
+    __shared__ int waveCnt[U][4];
     const int p = blockIdx.x;
     const PairRec pr = pairs[p];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 *rowKey = best + pr.bestRow;
     const u64 *colKey = best + pr.bestCol;
-    int2 *dst = WRITE ? out + offsets[p] : nullptr;
+    const int64_t first = WRITE ? offsets[p] : 0;
+    int2 *dst = WRITE ? out + first : nullptr;
     int running = 0;
-    for (int base = 0; base < pr.nA; base += 256) {
-        const int i = base + tid;
-        bool ok = false;
-        int j = -1;
-        if (i < pr.nA) {
-            const u64 kr = rowKey[i];
-            if (kr != 0) {
-                j = (int)(0xFFFFFFFFu - (unsigned)kr);
-                const u64 kc = colKey[j];
-                ok = kc != 0 && (int)(0xFFFFFFFFu - (unsigned)kc) == i;
-            }
-            if (WRITE && m1out) m1out[i] = j;
-        }
-        const u64 mask = __builtin_amdgcn_ballot_w64(ok);
-        const int prefix = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) waveCnt[wave] = __builtin_popcountll(mask);
-        __syncthreads();
-        int off = running, tot = 0;
+    for (int base = 0; base < pr.nA; base += 256 * U) {
+        u64 kr[U], kc[U];
+        int j[U], prefix[U];
+        bool ok[U];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k < wave) off += waveCnt[k];
-            tot += waveCnt[k];
+        for (int u = 0; u < U; u++) {
+            const int i = base + u * 256 + tid;
+            kr[u] = (i < pr.nA) ? rowKey[i] : 0;
         }
-        if (WRITE && ok) dst[off + prefix] = make_int2(i, j);
-        running += tot;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            j[u] = kr[u] ? (int)(0xFFFFFFFFu - (unsigned)kr[u]) : -1;
+            kc[u] = kr[u] ? colKey[j[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = base + u * 256 + tid;
+            ok[u] = kc[u] != 0 && (int)(0xFFFFFFFFu - (unsigned)kc[u]) == i;
+            if (WRITE && m1out && i < pr.nA) m1out[i] = j[u];
+            const u64 mask = __builtin_amdgcn_ballot_w64(ok[u]);
+            prefix[u] = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) waveCnt[u][wave] = __builtin_popcountll(mask);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int off = running, tot = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < wave) off += waveCnt[u][k];
+                tot += waveCnt[u][k];
+            }
+            if (WRITE && ok[u]) dst[off + prefix[u]] = make_int2(base + u * 256 + tid, j[u]);
+            running += tot;
+        }
         __syncthreads();
     }
     if (!WRITE && tid == 0) counts[p] = running;
+    if (WRITE && tid == 0) {
+        if (offsetsOut) offsetsOut[p + 1] = first + running;
+        if (totalOut) totalOut[0] = running;
+    }
     if (WRITE && m2out) {
-        for (int j = tid; j < pr.nB; j += 256) {
-            const u64 kc = colKey[j];
-            m2out[j] = kc ? (int)(0xFFFFFFFFu - (unsigned)kc) : -1;
+        for (int j2 = tid; j2 < pr.nB; j2 += 256) {
+            const u64 k2 = colKey[j2];
+            m2out[j2] = k2 ? (int)(0xFFFFFFFFu - (unsigned)k2) : -1;
         }
     }
 }

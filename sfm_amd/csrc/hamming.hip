@@ -429,12 +429,12 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
         }
         hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
                            res->counts.as<int>(), (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr,
-                           (int32_t *)nullptr);
+                           (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
         hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, res->counts.as<int>(), np,
                            res->offsets.as<int64_t>(), (int64_t)c0);
         hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best, (int *)nullptr,
                            res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(), (int32_t *)nullptr,
-                           (int32_t *)nullptr);
+                           (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
         SFM_HIP(ctx, hipGetLastError());
     }
     return SFM_OK;

@@ -26,7 +26,9 @@
 // reference's for any finite input, not only for integer-valued SIFT descriptors.
 #include "match_types.h"
 
+#include <initializer_list>
 #include <type_traits>
+#include <utility>
 
 // Every fp32/fp64 operation of the exact pass must be the one written: no fused multiply-adds.
 #pragma clang fp contract(off)
@@ -48,63 +50,138 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 // ingest
 // ---------------------------------------------------------------------------------------
-// One thread per descriptor: normA += a[i]*a[i] in index order, no contraction
-// (match.hpp:38-43), then sqrtf.
-// normRange[2 * image] = 0x7FFFFFFF - bits of the smallest norm, [2 * image + 1] = bits of the largest (norms
-// inside the safe range only; both start at 0 and grow under atomicMax).
-__global__ void ingest_norm_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
-                                   int dim, float *__restrict__ norms, float *__restrict__ norms2, int *__restrict__ imageFlags,
-                                   int *__restrict__ normRange)
+// One thread per descriptor, the whole row in registers (all its loads in flight at once):
+//  - normA += a[i]*a[i] in index order, no contraction (match.hpp:38-43), then sqrtf;
+//  - the row divided by that norm, rounded to fp16 (rows whose norm is outside the safe range, and the
+//    padding beyond dim, are zero);
+//  - per image, over the unit-normalised rows: the largest |element| and the largest L1 norm
+//    (stats[2 * image], [2 * image + 1]; bit patterns of non-negative floats, so an integer max orders them),
+//    from which the int8 table takes its scale;
+//  - normRange[2 * image] = 0x7FFFFFFF - bits of the smallest norm, [2 * image + 1] = bits of the largest
+//    (norms inside the safe range only; both start at 0 and grow under atomicMax);
+//  - the image's flags.
+// A wave combines its 64 rows before it touches the per-image words.
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+template <bool VEC>
+__global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+                                                         int dim, float *__restrict__ norms, float *__restrict__ norms2,
+                                                         int *__restrict__ imageFlags, int *__restrict__ stats,
+                                                         int *__restrict__ normRange, _Float16 *__restrict__ desc16)
 {
     const ImageRec im = images[blockIdx.y];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= im.n) return;
-    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= im.n) return;
+    const bool valid = r < im.n;
+    const float *a = desc32 + (size_t)(im.row32 + (valid ? r : 0)) * dim;
+    float v[KDIM];
+    if constexpr (VEC) { // dim is a multiple of four: rows are 16-byte aligned
+#pragma unroll
+        for (int k = 0; k < KDIM; k += 4) {
+            float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k < dim) q = *reinterpret_cast<const float4 *>(a + k);
+            v[k] = q.x, v[k + 1] = q.y, v[k + 2] = q.z, v[k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KDIM; k++) v[k] = (k < dim) ? a[k] : 0.0f;
+    }
+    // (the zeros beyond dim change nothing below: x + 0 = x, max(x, 0) = x for x >= 0, and 0 is a byte)
     float normA = 0.0f;
     bool bytes = true;
-    for (int k = 0; k < dim; k++) {
-        normA = __fadd_rn(normA, __fmul_rn(a[k], a[k]));
-        bytes = bytes && a[k] >= 0.0f && a[k] <= 255.0f && a[k] == floorf(a[k]);
+#pragma unroll
+    for (int k = 0; k < KDIM; k++) {
+        normA = __fadd_rn(normA, __fmul_rn(v[k], v[k]));
+        bytes = bytes && v[k] >= 0.0f && v[k] <= 255.0f && v[k] == floorf(v[k]);
     }
     // sqrtf, not __fsqrt_rn: the latter compiles to the bare v_sqrt_f32 (1 ulp); sqrtf is correctly rounded
     // under -fhip-fp32-correctly-rounded-divide-sqrt, like std::sqrt on the host (match.hpp:45)
     const float s = sqrtf(normA);
-    norms[im.row32 + r] = s;
-    norms2[im.row32 + r] = normA; // the squared norm as the reference's loop accumulates it (L2 mode)
-    const bool inRange = (s >= 1e-12f) && (s <= 1e12f);
-    if (inRange) {
-        atomicMax(&normRange[2 * blockIdx.y], 0x7FFFFFFF - __float_as_int(s));
-        atomicMax(&normRange[2 * blockIdx.y + 1], __float_as_int(s));
+    const bool ok = (s >= 1e-12f) && (s <= 1e12f);
+    float mx = 0.0f, l1 = 0.0f;
+    _Float16 *out = desc16 + (size_t)(im.row16 + r) * KDIM;
+#pragma unroll
+    for (int k0 = 0; k0 < KDIM; k0 += 8) {
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float q = ok ? __fdiv_rn(v[k0 + e], s) : 0.0f;
+            h[e] = (_Float16)q;
+            mx = fmaxf(mx, fabsf(q));
+            l1 += fabsf(q);
+        }
+        if (valid) *reinterpret_cast<half8 *>(out + k0) = h;
     }
-    int f = bytes ? 0 : IMG_NOT_U8;
-    if (!inRange) {
-        f |= IMG_WILD_DOT;
-        if (s != 0.0f && s == s && s != INFINITY) f |= IMG_WILD_COS;
+    int f = 0;
+    if (valid) {
+        norms[im.row32 + r] = s;
+        norms2[im.row32 + r] = normA; // the squared norm as the reference's loop accumulates it (L2 mode)
+        f = bytes ? 0 : IMG_NOT_U8;
+        if (!ok) {
+            f |= IMG_WILD_DOT;
+            if (s != 0.0f && s == s && s != INFINITY) f |= IMG_WILD_COS;
+        }
     }
-    if (f) atomicOr(&imageFlags[blockIdx.y], f);
+    const bool in = valid && ok;
+    const int wMx = wave_max(in ? __float_as_int(mx) : 0);
+    const int wL1 = wave_max(in ? __float_as_int(l1 * 1.0001f) : 0); // the sum's own rounding
+    const int wLo = wave_max(in ? 0x7FFFFFFF - __float_as_int(s) : 0);
+    const int wHi = wave_max(in ? __float_as_int(s) : 0);
+    int wF = f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wF |= __shfl_xor(wF, d, 64);
+    if (threadIdx.x == 0) {
+        if (wMx) atomicMax(&stats[2 * blockIdx.y], wMx);
+        if (wL1) atomicMax(&stats[2 * blockIdx.y + 1], wL1);
+        if (wLo) atomicMax(&normRange[2 * blockIdx.y], wLo);
+        if (wHi) atomicMax(&normRange[2 * blockIdx.y + 1], wHi);
+        if (wF) atomicOr(&imageFlags[blockIdx.y], wF);
+    }
 }
 
-// One thread per 8 elements of the fp16 table: a / norm rounded to fp16; rows whose norm is
-// outside the safe range, and the padding beyond dim, are zero.
-__global__ void ingest_f16_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
-                                  const float *__restrict__ norms, int dim, _Float16 *__restrict__ desc16)
+// Several buffers cleared by one launch (block row y clears range y; sizes are multiples of four bytes).
+#define CLEAR_RANGES 6
+struct ClearRanges {
+    void *p[CLEAR_RANGES];
+    unsigned long long bytes[CLEAR_RANGES];
+};
+__global__ __launch_bounds__(256) void clear_ranges_kernel(const ClearRanges r)
 {
-    const ImageRec im = images[blockIdx.y];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = t >> 4, k0 = (t & 15) * 8;
-    if (r >= im.n) return;
-    const float s = norms[im.row32 + r];
-    const bool ok = (s >= 1e-12f) && (s <= 1e12f);
-    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
-    half8 out;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int k = k0 + e;
-        float v = 0.0f;
-        if (ok && k < dim) v = __fdiv_rn(a[k], s);
-        out[e] = (_Float16)v;
+    unsigned char *base = reinterpret_cast<unsigned char *>(r.p[blockIdx.y]);
+    const size_t bytes = r.bytes[blockIdx.y];
+    const size_t toAligned = (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
+    const size_t head = bytes < toAligned ? bytes : toAligned;
+    const size_t n16 = (bytes - head) / 16;
+    uint4 *mid = reinterpret_cast<uint4 *>(base + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) mid[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0) {
+        const size_t tail0 = head + n16 * 16;
+        for (size_t i = threadIdx.x * 4; i < head; i += 1024) *reinterpret_cast<unsigned *>(base + i) = 0;
+        for (size_t i = tail0 + threadIdx.x * 4; i < bytes; i += 1024) *reinterpret_cast<unsigned *>(base + i) = 0;
     }
-    *reinterpret_cast<half8 *>(desc16 + (size_t)(im.row16 + r) * KDIM + k0) = out;
+}
+// Clears up to CLEAR_RANGES (pointer, bytes) ranges on a stream with one launch; ranges of zero bytes are skipped.
+static hipError_t clear_ranges(hipStream_t st, std::initializer_list<std::pair<void *, size_t>> ranges)
+{
+    ClearRanges r;
+    int n = 0;
+    size_t most = 0;
+    for (const auto &x : ranges) {
+        if (x.second == 0) continue;
+        if (n == CLEAR_RANGES || (x.second & 3)) return hipErrorInvalidValue;
+        r.p[n] = x.first;
+        r.bytes[n] = x.second;
+        most = std::max(most, x.second);
+        n++;
+    }
+    if (n == 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<size_t>(1024, (most / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(clear_ranges_kernel, dim3(gx, n), dim3(256), 0, st, r);
+    return hipGetLastError();
 }
 
 // Byte copy of a table whose elements are all integers in [0, 255] (SIFT descriptors as OpenCV
@@ -131,30 +208,18 @@ __global__ void expand_u8_kernel(const unsigned char *__restrict__ src, int64_t 
     if (t < n) dst[t] = (float)src[t];
 }
 
-// Per image, over its unit-normalised descriptors a / |a|: the largest |element| and the largest L1
-// norm (as int bit patterns of non-negative floats, so atomicMax orders them).  One thread per descriptor.
-__global__ void ingest_stats_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
-                                    const float *__restrict__ norms, int dim, int *__restrict__ stats)
+// Scale of an image's int8 table from the largest |element| of its unit-normalised descriptors (bit pattern).
+__host__ __device__ __forceinline__ float int8_scale(int largestBits)
 {
-    const ImageRec im = images[blockIdx.y];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= im.n) return;
-    const float s = norms[im.row32 + r];
-    if (!((s >= 1e-12f) && (s <= 1e12f))) return;
-    const float *a = desc32 + (size_t)(im.row32 + r) * dim;
-    float mx = 0.0f, l1 = 0.0f;
-    for (int k = 0; k < dim; k++) {
-        const float v = fabsf(__fdiv_rn(a[k], s));
-        mx = fmaxf(mx, v);
-        l1 += v;
-    }
-    atomicMax(&stats[2 * blockIdx.y], __float_as_int(mx));
-    atomicMax(&stats[2 * blockIdx.y + 1], __float_as_int(l1 * 1.0001f)); // the sum's own rounding
+    float mx;
+    memcpy(&mx, &largestBits, 4);
+    return (mx > 0.0f) ? 127.0f / mx : 1.0f;
 }
 
-// One thread per 16 elements of the int8 table: round(a / norm * scale), scale = ImageRec::scale8.
+// One thread per 16 elements of the int8 table: round(a / norm * scale), scale from the image's statistics.
 __global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
-                                 const float *__restrict__ norms, int dim, signed char *__restrict__ desc8)
+                                 const float *__restrict__ norms, int dim, const int *__restrict__ stats,
+                                 signed char *__restrict__ desc8)
 {
     const ImageRec im = images[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,7 +227,7 @@ __global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRe
     if (r >= im.n) return;
     const float s = norms[im.row32 + r];
     const bool ok = (s >= 1e-12f) && (s <= 1e12f);
-    const float scale = __int_as_float(im.pad);
+    const float scale = int8_scale(stats[2 * blockIdx.y]);
     const float *a = desc32 + (size_t)(im.row32 + r) * dim;
     int4v out;
 #pragma unroll
@@ -179,6 +244,79 @@ __global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRe
         out[w] = (int)packed;
     }
     *reinterpret_cast<int4v *>(desc8 + (size_t)(im.row16 + r) * 128 + k0) = out;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-pair candidate bounds
+// ---------------------------------------------------------------------------------------
+// One thread per pair of a chunk: the bound on the approximate cosine (thr_m) and on the int8 sum (thr_i)
+// from the two images' statistics, which never leave the device.
+struct BoundArgs {
+    const int *stats; // [n][2] largest |element| and L1 norm, then [n][2] norm range (bit patterns, see sfm_imageset)
+    const int *flags; // [n] IMG_*
+    int nImages;
+    int dim;
+    int metric;
+    float threshold;
+    float ratio;
+};
+__global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ pairs, int nPairs, const BoundArgs b)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPairs) return;
+    const int ia = pairs[p].ia, ib = pairs[p].ib;
+    const float threshold = b.threshold, ratio = b.ratio;
+    const int wildMask = (b.metric == SFM_METRIC_COSINE) ? IMG_WILD_COS : IMG_WILD_DOT;
+    bool wild = ((b.flags[ia] | b.flags[ib]) & wildMask) != 0;
+    float thrp = threshold > 0.0f ? threshold : 0.0f;
+    if (b.metric == SFM_METRIC_L2) {
+        // d^2 < T  =>  a.b > (|a|^2 + |b|^2 - T) / 2  =>  cos > 1 - T / (2 |a| |b|)   (|a|^2 + |b|^2 >= 2 |a| |b|)
+        //          >=  1 - T / (2 minA minB).  The fp32 evaluation of d^2 is within 1e-4 (maxA^2 + maxB^2) of the
+        // exact one; the ratio mode collects down to T / ratio^2 (a rival at d2 undoes a best at d1 < T
+        // only if d2 <= d1 / ratio^2).
+        const int *range = b.stats + 2 * (size_t)b.nImages;
+        const double minA = (double)__int_as_float(0x7FFFFFFF - range[2 * ia]), maxA = (double)__int_as_float(range[2 * ia + 1]);
+        const double minB = (double)__int_as_float(0x7FFFFFFF - range[2 * ib]), maxB = (double)__int_as_float(range[2 * ib + 1]);
+        const double lo = minA * minB; // NaN when an image has no descriptor inside the safe range
+        const double hi2 = maxA * maxA + maxB * maxB;
+        double T = (double)threshold;
+        if (ratio > 0.0f) T = T / ((double)ratio * ratio);
+        const double c = 1.0 - (T + 1e-4 * hi2) / (2.0 * lo) - 1e-6;
+        const bool open = !(lo > 0.0) || !(c == c) || c < -1.5; // no cosine bound holds for this pair
+        thrp = open ? 0.0f : (float)c;
+        wild = wild || open;
+    }
+    // Ratio mode: a row whose best has similarity s1 > threshold is undone by any column at or
+    // above 1 - (1 - s1) / ratio^2, which is more than 1 - (1 - threshold) / ratio^2: the bound
+    // pass collects down to there, and the exact pass still applies the threshold itself.
+    if (b.metric != SFM_METRIC_L2 && ratio > 0.0f && threshold == threshold) {
+        const float t = (float)(1.0 - (1.0 - (double)thrp) / ((double)ratio * ratio) - 1e-6);
+        thrp = t > -2.0f ? t : -2.0f;
+    }
+    float thr_m;
+    if (wild)
+        thr_m = -INFINITY;
+    else if (b.metric == SFM_METRIC_DOT)
+        thr_m = (thrp == 0.0f) ? -SIM_MARGIN : 0.0f; // a positive bound on the dot product is tested per cell
+    else
+        thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN; // (L2: thrp may be negative here)
+    // Bound on the int8 dot product S = sum q_k p_k, q = round(a_hat * sA), p = round(b_hat * sB):
+    // |a_hat.b_hat * sA * sB - S| <= 0.5001 (sA L1_A + sB L1_B) + 0.7505 dim  (rounding errors
+    // e, f with |e|, |f| <= 0.5001 against |q| <= sA |a_hat| + 0.5001), and the reference's cosine
+    // is within 1e-4 of a_hat.b_hat.
+    const double sA = (double)int8_scale(b.stats[2 * ia]), sB = (double)int8_scale(b.stats[2 * ib]);
+    const double l1A = (double)__int_as_float(b.stats[2 * ia + 1]), l1B = (double)__int_as_float(b.stats[2 * ib + 1]);
+    const double err = 0.5001 * (sA * l1A + sB * l1B) + 0.7505 * b.dim;
+    const double t = ((double)thrp - 1e-4) * sA * sB - err;
+    int thr_i;
+    if (threshold != threshold)
+        thr_i = INT_MAX;
+    else if (wild || b.metric == SFM_METRIC_DOT || !(t > -1e9))
+        thr_i = -(1 << 30);
+    else
+        thr_i = (int)floor(t < 2.0e9 ? t : 2.0e9);
+    pairs[p].thr_m = thr_m;
+    pairs[p].thr_i = thr_i;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -541,8 +679,14 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     if (w.x < 0) return;
     if (g.onlyFlagged && g.pairOvf[w.x] != g.onlyFlagged) return; // later passes: pairs an earlier pass gave up on
     PairRec pr = g.pairs[w.x];
-    // slices of the pair's candidate list: one per wave of a strict pass, or one per wave of
-    // both orientations of the general pass
+    // Small launches of the strict passes cut the columns into parts, one block per (row block, part): a pair
+    // of 8192 x 8192 is 32 row blocks, far too few for 256 CUs.  The filtered passes need all columns of a row
+    // in one wave, in order: they take the items of part 0 and walk every column.
+    const int colParts = GENERAL ? 1 : max(g.colSplit, 1);
+    const int colPart = w.y >> 24, rowBlock = w.y & 0xFFFFFF;
+    if (GENERAL && colPart != 0) return;
+    // slices of the pair's candidate list: one per wave (and column part) of a strict pass, or one per wave
+    // of both orientations of the general pass
     const int nQ0 = ((pr.nA + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
     const int nQ1 = ((pr.nB + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
     if (GENERAL && g.orient) { // image B's rows stay in registers, image A streams
@@ -553,7 +697,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rowBase = w.y * SIM_BLOCK_ROWS + wave * SIM_WAVE_ROWS;
+    const int rowBase = rowBlock * SIM_BLOCK_ROWS + wave * SIM_WAVE_ROWS;
 
     const unsigned char *table = I8 ? reinterpret_cast<const unsigned char *>(g.desc8) : reinterpret_cast<const unsigned char *>(g.desc16);
     const unsigned char *Arows = table + (size_t)(pr.rowA16 + rowBase) * ROWB;
@@ -569,7 +713,11 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         for (int s = 0; s < NKB; s++)
             a[t][s] = *reinterpret_cast<const Frag *>(Arows + (size_t)(t * 16 + (lane & 15)) * ROWB + (s * 4 + (lane >> 4)) * 16);
 
-    const int nChunks = (pr.nB + SIM_BN - 1) / SIM_BN;
+    // this block's steps of SIM_BN columns: [chunk0, nChunks)
+    const int allChunks = (pr.nB + SIM_BN - 1) / SIM_BN;
+    const int perPart = (allChunks + colParts - 1) / colParts;
+    const int chunk0 = colPart * perPart;
+    const int nChunks = min(allChunks, chunk0 + perPart);
     // the bound is the same for the whole block: keep it (and the branch on it) scalar
     const float thr_m = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m)));
     const int thr_i = __builtin_amdgcn_readfirstlane(pr.thr_i);
@@ -598,7 +746,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     };
     if constexpr (GENERAL) {
         for (int rr = tid; rr < SIM_BLOCK_ROWS; rr += SIM_WAVES * 64) {
-            ptsRow[rr] = g.pts[pr.rowA32 + min(w.y * SIM_BLOCK_ROWS + rr, pr.nA - 1)];
+            ptsRow[rr] = g.pts[pr.rowA32 + min(rowBlock * SIM_BLOCK_ROWS + rr, pr.nA - 1)];
             rowBound[rr] = 0;
         }
     }
@@ -625,8 +773,8 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             }
     };
     // this wave's slice of the pair's candidate list
-    const int nQueues = GENERAL ? nQ0 + nQ1 : nQ0;
-    const int queueId = ((GENERAL && g.orient) ? nQ0 : 0) + w.y * SIM_WAVES + wave;
+    const int nQueues = GENERAL ? nQ0 + nQ1 : nQ0 * colParts;
+    const int queueId = ((GENERAL && g.orient) ? nQ0 : colPart * nQ0) + rowBlock * SIM_WAVES + wave;
     float localLo[GENERAL ? AccT::NV : 1];
 #pragma unroll
     for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
@@ -671,9 +819,9 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         }
         if (!(ABL & 1)) __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
     };
-    dma_issue(0, 0);
+    if (chunk0 < nChunks) dma_issue(chunk0, 0);
     __syncthreads();
-    for (int c = 0; c < nChunks; c += 2) {
+    for (int c = chunk0; c < nChunks; c += 2) {
         step(c, 0);
         if (c + 1 < nChunks) step(c + 1, (ABL & 1) ? 0 : 1);
     }
@@ -743,7 +891,7 @@ __device__ __forceinline__ int pair_queues(const MatchArgs &g, const PairRec &pr
 {
     const int nQ0 = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
     const int nQ1 = ((pr.nB + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
-    return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0;
+    return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0 * max(g.colSplit, 1);
 }
 
 // One wave per candidate slice, four slices per block.  RATIO: the second sweep of the ratio mode;
@@ -995,7 +1143,6 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
     s->norms2.release();
     if (s->owns_pts) s->pts.release();
     s->imageRecs.release();
-    s->imageFlags.release();
     sfm_ctx *owner = s->ctx;
     delete s;
     sfm_ctx_release(owner);
@@ -1004,7 +1151,7 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
 extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
 {
     if (!s) return 0;
-    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->desc8u.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageFlags.cap);
+    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->desc8u.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageStats.cap);
 }
 
 // Two host tables that together form the set's table (image 0 then image 1): the single-pair entry
@@ -1020,7 +1167,7 @@ struct TwoParts {
 static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, const float *desc,
                           const double *pts, int dim, bool on_device, sfm_imageset **set_out,
                           const unsigned char *desc_bytes = nullptr, sfm_imageset **reuse = nullptr,
-                          const TwoParts *parts = nullptr)
+                          const TwoParts *parts = nullptr, bool no_wait = false)
 {
     if (!ctx || !set_out) return SFM_ERR_INVALID_ARG;
     *set_out = nullptr;
@@ -1037,8 +1184,6 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     if (reuse) *reuse = nullptr;
     if (fresh) sfm_ctx_retain(ctx);
     s->ctx = ctx;
-    s->scale8.clear();
-    s->l1max.clear();
     s->n_images = n_images;
     s->dim = dim;
     s->images.resize(n_images);
@@ -1110,61 +1255,39 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     }
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
     SET_HIP(s->desc8.reserve((size_t)r16 * 128));
-    SET_HIP(s->imageStats.reserve((size_t)(n_images ? n_images : 1) * 4 * sizeof(int))); // [n][2] int8 statistics, then [n][2] norm range
+    const size_t nImg = (size_t)(n_images ? n_images : 1);
+    SET_HIP(s->imageStats.reserve(nImg * 5 * sizeof(int))); // [n][2] int8 statistics, [n][2] norm range, [n] flags
     SET_HIP(s->norms2.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
-    SET_HIP(hipMemsetAsync(s->desc8.p, 0, (size_t)r16 * 128, ctx->stream));
-    SET_HIP(hipMemsetAsync(s->imageStats.p, 0, (size_t)(n_images ? n_images : 1) * 4 * sizeof(int), ctx->stream));
     SET_HIP(s->norms.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
-    SET_HIP(s->imageRecs.reserve((size_t)(n_images ? n_images : 1) * sizeof(ImageRec)));
-    SET_HIP(s->imageFlags.reserve((size_t)(n_images ? n_images : 1) * sizeof(int)));
-    SET_HIP(hipMemsetAsync(s->desc16.p, 0, (size_t)r16 * KDIM * sizeof(_Float16), ctx->stream));
-    SET_HIP(hipMemsetAsync(s->imageFlags.p, 0, (size_t)(n_images ? n_images : 1) * sizeof(int), ctx->stream));
+    SET_HIP(s->imageRecs.reserve(nImg * sizeof(ImageRec)));
+    // the padding rows of both tables must read as zero, and the per-image words start at zero
+    SET_HIP(clear_ranges(ctx->stream, {{s->desc8.p, (size_t)r16 * 128},
+                                       {s->desc16.p, (size_t)r16 * KDIM * sizeof(_Float16)},
+                                       {s->imageStats.p, nImg * 5 * sizeof(int)}}));
+    int *const imageFlags = s->imageStats.as<int>() + 4 * nImg;
     s->flags.assign(n_images, 0);
     if (n_images > 0 && maxN > 0) {
         SET_HIP(hipMemcpyAsync(s->imageRecs.p, s->images.data(), (size_t)n_images * sizeof(ImageRec),
                                hipMemcpyHostToDevice, ctx->stream));
-        dim3 g1((maxN + 255) / 256, n_images);
-        hipLaunchKernelGGL(ingest_norm_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
-                           s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->norms2.as<float>(), s->imageFlags.as<int>(),
-                           s->imageStats.as<int>() + 2 * (size_t)n_images);
-        dim3 g2(((int64_t)maxN * 16 + 255) / 256, n_images);
-        hipLaunchKernelGGL(ingest_f16_kernel, g2, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
-                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->desc16.as<_Float16>());
-        SET_HIP(hipGetLastError());
-        SET_HIP(hipMemcpyAsync(s->flags.data(), s->imageFlags.p, (size_t)n_images * sizeof(int),
-                               hipMemcpyDeviceToHost, ctx->stream));
-        // (flags arrive with the synchronisation below)
-        // int8 table: per-image scale from the largest unit-normalised element
-        hipLaunchKernelGGL(ingest_stats_kernel, g1, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
-                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>());
-        std::vector<int> stats((size_t)n_images * 4);
-        SET_HIP(hipMemcpyAsync(stats.data(), s->imageStats.p, stats.size() * sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
-        SET_HIP(hipStreamSynchronize(ctx->stream));
-        s->scale8.assign(n_images, 1.0f);
-        s->l1max.assign(n_images, 0.0f);
-        s->normMin.assign(n_images, 0.0f);
-        s->normMax.assign(n_images, 0.0f);
-        for (int i = 0; i < n_images; i++) {
-            float mx, l1;
-            memcpy(&mx, &stats[2 * i], 4);
-            memcpy(&l1, &stats[2 * i + 1], 4);
-            s->scale8[i] = (mx > 0.0f) ? 127.0f / mx : 1.0f;
-            s->l1max[i] = l1;
-            const int lo = 0x7FFFFFFF - stats[2 * (size_t)n_images + 2 * i], hi = stats[2 * (size_t)n_images + 2 * i + 1];
-            memcpy(&s->normMin[i], &lo, 4); // NaN pattern when the image has no in-range descriptor
-            memcpy(&s->normMax[i], &hi, 4);
-            memcpy(&s->images[i].pad, &s->scale8[i], 4);
-        }
-        SET_HIP(hipMemcpyAsync(s->imageRecs.p, s->images.data(), (size_t)n_images * sizeof(ImageRec),
-                               hipMemcpyHostToDevice, ctx->stream));
+        dim3 g1((maxN + 63) / 64, n_images);
+        hipLaunchKernelGGL(((dim & 3) == 0 ? ingest_rows_kernel<true> : ingest_rows_kernel<false>), g1, dim3(64), 0, ctx->stream,
+                           s->desc32.as<float>(), s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->norms2.as<float>(),
+                           imageFlags, s->imageStats.as<int>(), s->imageStats.as<int>() + 2 * nImg, s->desc16.as<_Float16>());
+        // int8 table: per-image scale from the largest unit-normalised element (statistics stay on the device)
         dim3 g3(((int64_t)maxN * 8 + 255) / 256, n_images);
         hipLaunchKernelGGL(ingest_i8_kernel, g3, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
-                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->desc8.as<signed char>());
+                           s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>(),
+                           s->desc8.as<signed char>());
         SET_HIP(hipGetLastError());
+        if (!no_wait) { // the flags decide below whether the exact pass gets a byte copy
+            SET_HIP(hipMemcpyAsync(s->flags.data(), imageFlags, (size_t)n_images * sizeof(int),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+            SET_HIP(hipStreamSynchronize(ctx->stream));
+        }
     }
+    s->flags_on_host = !no_wait;
     // byte copy for the exact pass when the whole table is byte-valued
-    s->u8_exact = dim == 128 && r32 > 0;
+    s->u8_exact = dim == 128 && r32 > 0 && !no_wait;
     for (int i = 0; i < n_images; i++) s->u8_exact = s->u8_exact && !(s->flags[i] & IMG_NOT_U8);
     if (s->u8_exact) {
         SET_HIP(s->desc8u.reserve((size_t)r32 * 128));
@@ -1172,13 +1295,8 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
                            s->desc32.as<float>(), r32, s->desc8u.as<unsigned char>());
         SET_HIP(hipGetLastError());
     }
-    if (s->scale8.empty()) {
-        s->scale8.assign(n_images, 1.0f);
-        s->l1max.assign(n_images, 0.0f);
-        s->normMin.assign(n_images, 0.0f);
-        s->normMax.assign(n_images, 0.0f);
-    }
-    SET_HIP(hipStreamSynchronize(ctx->stream));
+    // The caller of a build that does not wait goes on queueing work on the same stream and waits once, at its end.
+    if (!no_wait) SET_HIP(hipStreamSynchronize(ctx->stream));
 #undef SET_HIP
     *set_out = s;
     return SFM_OK;
@@ -1211,7 +1329,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     (void)hipStreamSynchronize(r->ctx->stream2); // a call that failed half-way may have left work of this result there
     if (r->done) (void)hipEventDestroy(r->done);
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
-                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->m2, &r->kill};
+                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill};
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
@@ -1225,7 +1343,7 @@ int sfm_num_sim_variants() { return kNumSimVariants; }
 
 static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
                             int metric, float threshold, float maxDistSq, sfm_match_result **result_inout,
-                            bool want_m1m2, float ratio = 0.0f)
+                            bool want_m1m2, float ratio = 0.0f, bool result_idle = false)
 {
     if (!ctx || !set || !result_inout) return SFM_ERR_INVALID_ARG;
     if (ratio != 0.0f && !(ratio > 0.0f && ratio <= 1.0f))
@@ -1247,7 +1365,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         *result_inout = res;
     } else if (res->ctx != ctx) {
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: result belongs to another context");
-    } else {
+    } else if (!result_idle) {
         // the staging buffers of a reused result may still be the source of copies in flight (on the second
         // stream too, when an earlier call failed between its fork and its join)
         SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1279,10 +1397,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         if (nA <= 0 || nB <= 0) return 0;
         return ((orient ? nB : nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
     };
+    int64_t mostBlocks = 0; // row blocks of image A in the chunk that has most
     for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
         const int c1 = std::min(n_pairs, c0 + chunkPairs);
-        int64_t bestOff = 0;
-        int64_t queueLen[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+        int64_t bestOff = 0, blocks = 0;
         for (int p = c0; p < c1; p++) {
             const int ia = pair_list[2 * p], ib = pair_list[2 * p + 1];
             if (ia < 0 || ia >= set->n_images || ib < 0 || ib >= set->n_images)
@@ -1292,9 +1410,37 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             outTotalCap += std::min(nA, nB);
             maxNA = std::max(maxNA, nA);
             maxNB = std::max(maxNB, nB);
-            for (int o = 0; o < 2; o++) queueLen[o][(p - c0) & 7] += row_blocks(nA, nB, o);
+            blocks += row_blocks(nA, nB, 0);
         }
         maxBest = std::max(maxBest, bestOff);
+        mostBlocks = std::max(mostBlocks, blocks);
+    }
+    // Column parts of the strict passes (see sim_block): a launch that would leave most of the device idle, or
+    // fill it unevenly with a few long blocks, is cut into more and shorter ones.  Every part keeps at least
+    // eight steps of 64 columns, and the slices of a pair's candidate list stay within what the exact pass
+    // numbers in one block (1024).
+    int colSplit = 1;
+    if (metric != SFM_METRIC_DOT && mostBlocks > 0) {
+        const int64_t want = 16 * (int64_t)ctx->n_cus; // three rounds of five blocks per CU: short blocks level the CUs out
+        const int stepsB = (maxNB + SIM_BN - 1) / SIM_BN;
+        const int queuesA = ((maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
+        while (colSplit < 16 && mostBlocks * colSplit < want && stepsB / (2 * colSplit) >= 8 &&
+               (set->dim != 128 || queuesA * 2 * colSplit <= 1024))
+            colSplit *= 2;
+        if (ctx->match_col_split > 0) colSplit = ctx->match_col_split;
+    }
+    // Work lists: block b of a chunk's launch takes entry b.  Blocks b and b + 8 run on the same XCD (round-robin
+    // dispatch), so the row blocks that stream the same columns (one pair, one column part) are dealt to one
+    // residue class mod 8 and share that XCD's L2 copy of them.
+    auto residue = [&](int pairInChunk, int part) { return (pairInChunk + part) & 7; };
+    for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
+        const int c1 = std::min(n_pairs, c0 + chunkPairs);
+        int64_t queueLen[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+        for (int p = c0; p < c1; p++) {
+            const int nA = set->images[pair_list[2 * p]].n, nB = set->images[pair_list[2 * p + 1]].n;
+            for (int part = 0; part < colSplit; part++) queueLen[0][residue(p - c0, part)] += row_blocks(nA, nB, 0);
+            queueLen[1][(p - c0) & 7] += row_blocks(nA, nB, 1);
+        }
         for (int o = 0; o < 2; o++) {
             int64_t qmax = 0;
             for (int x = 0; x < 8; x++) qmax = std::max(qmax, queueLen[o][x]);
@@ -1306,9 +1452,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->hostWork.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
     int2 *work = res->hostWork.as<int2>();
 
-    // Records of one chunk, and its work lists: block b of a chunk takes entry b.  Blocks b and
-    // b + 8 run on the same XCD (round-robin dispatch), so every pair's row blocks are dealt to one
-    // residue class mod 8 and share that XCD's L2 copy of the streamed image.
+    // Records of one chunk, and its work lists.
     auto prepare_chunk = [&](int c0, int c1, size_t ci) {
         int64_t bestOff = 0;
         for (int p = c0; p < c1; p++) {
@@ -1325,50 +1469,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             r.bestCol = bestOff + A.n;
             bestOff += (int64_t)A.n + B.n;
             r.chunkLocal = p - c0;
-            const int wildMask = (metric == SFM_METRIC_COSINE) ? IMG_WILD_COS : IMG_WILD_DOT;
-            bool wild = ((set->flags[ia] | set->flags[ib]) & wildMask) != 0;
-            float thrp = threshold > 0.0f ? threshold : 0.0f;
-            bool l2Open = false; // L2: no cosine bound holds for this pair
-            if (metric == SFM_METRIC_L2) {
-                // d^2 < T  =>  a.b > (|a|^2 + |b|^2 - T) / 2  =>  cos > 1 - T / (2 |a| |b|)   (|a|^2 + |b|^2 >= 2 |a| |b|)
-                //          >=  1 - T / (2 minA minB).  The fp32 evaluation of d^2 is within 1e-4 (maxA^2 + maxB^2) of the
-                // exact one; the ratio mode collects down to T / ratio^2 (a rival at d2 undoes a best at d1 < T
-                // only if d2 <= d1 / ratio^2).
-                const double lo = (double)set->normMin[ia] * (double)set->normMin[ib];
-                const double hi2 = (double)set->normMax[ia] * set->normMax[ia] + (double)set->normMax[ib] * set->normMax[ib];
-                double T = (double)threshold;
-                if (ratio > 0.0f) T = T / ((double)ratio * ratio);
-                const double c = 1.0 - (T + 1e-4 * hi2) / (2.0 * lo) - 1e-6;
-                if (!(lo > 0.0) || !(c == c) || c < -1.5) l2Open = true;
-                thrp = l2Open ? 0.0f : (float)std::max(c, -1.5);
-            }
-            // Ratio mode: a row whose best has similarity s1 > threshold is undone by any column at or
-            // above 1 - (1 - s1) / ratio^2, which is more than 1 - (1 - threshold) / ratio^2: the bound
-            // pass collects down to there, and the exact pass still applies the threshold itself.
-            if (metric != SFM_METRIC_L2 && ratio > 0.0f && threshold == threshold)
-                thrp = std::max(-2.0f, (float)(1.0 - (1.0 - (double)thrp) / ((double)ratio * ratio) - 1e-6));
-            wild = wild || l2Open;
-            if (wild)
-                r.thr_m = -INFINITY;
-            else if (metric == SFM_METRIC_L2)
-                r.thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN; // thrp may be negative here
-            else if (metric == SFM_METRIC_COSINE)
-                r.thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN;
-            else
-                r.thr_m = (thrp == 0.0f) ? -SIM_MARGIN : 0.0f; // DOT with a positive bound tests per cell
-            // Bound on the int8 dot product S = sum q_k p_k, q = round(a_hat * sA), p = round(b_hat * sB):
-            // |a_hat.b_hat * sA * sB - S| <= 0.5001 (sA L1_A + sB L1_B) + 0.7505 dim  (rounding errors
-            // e, f with |e|, |f| <= 0.5001 against |q| <= sA |a_hat| + 0.5001), and the reference's cosine
-            // is within 1e-4 of a_hat.b_hat.
-            const double sA = set->scale8[ia], sB = set->scale8[ib];
-            const double err = 0.5001 * (sA * set->l1max[ia] + sB * set->l1max[ib]) + 0.7505 * set->dim;
-            const double t = ((double)thrp - 1e-4) * sA * sB - err;
-            if (threshold != threshold)
-                r.thr_i = INT_MAX;
-            else if (wild || metric == SFM_METRIC_DOT || !(t > -1e9))
-                r.thr_i = -(1 << 30);
-            else
-                r.thr_i = (int32_t)std::floor(std::min(t, 2.0e9));
+            r.ia = ia;
+            r.ib = ib;
+            r.thr_m = 0.0f; // pair_bounds_kernel fills the two bounds in on the device
+            r.thr_i = 0;
             r.pad_ = 0;
         }
         for (int o = 0; o < 2; o++) {
@@ -1377,9 +1481,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             for (int k = 0; k < cnt; k++) wl[k] = make_int2(-1, 0);
             int64_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int p = c0; p < c1; p++) {
-                const int x = (p - c0) & 7;
                 const int nb = row_blocks(recs[p].nA, recs[p].nB, o);
-                for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb);
+                for (int part = 0; part < (o == 0 ? colSplit : 1); part++) {
+                    const int x = o == 0 ? residue(p - c0, part) : (p - c0) & 7;
+                    for (int rb = 0; rb < nb; rb++) wl[(pos[x]++) * 8 + x] = make_int2(p - c0, rb | (part << 24));
+                }
             }
         }
     };
@@ -1402,7 +1508,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     const int sets = overlap ? std::min(3, nChunks) : 1;
     const size_t candSet = (size_t)round_up((int64_t)((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)), 256);
     SFM_HIP(ctx, res->cand.reserve(candSet * sets));
-    const int maxQueues = std::max(1, (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
+    const int maxQueues = std::max(1, std::max((maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS,
+                                               (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS * colSplit)) * wavesPerBlock;
     const size_t candCountSet = (size_t)round_up((int64_t)((size_t)chunkPairs * maxQueues * sizeof(int)), 256);
     SFM_HIP(ctx, res->candCount.reserve(candCountSet * sets));
     const size_t pairOvfSet = (size_t)round_up((int64_t)((size_t)(chunkPairs + 4) * sizeof(int)), 256); // flags, then how often each value was set
@@ -1416,13 +1523,23 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
     const size_t killSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(int)), 256);
     if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killSet * sets));
+    // The single-pair entry point fetches everything with one copy: its count, the per-row and per-column bests
+    // and the list lie side by side, [count: 16 B][m1: nA][m2: nB][(i, j): min(nA, nB)].
+    unsigned char *packed = nullptr;
+    int32_t *packedM1 = nullptr, *packedM2 = nullptr;
+    int2 *packedPairs = nullptr;
     if (want_m1m2) {
-        SFM_HIP(ctx, res->m1.reserve((size_t)(maxNA ? maxNA : 1) * sizeof(int32_t)));
-        SFM_HIP(ctx, res->m2.reserve((size_t)(maxNB ? maxNB : 1) * sizeof(int32_t)));
+        if (n_pairs != 1) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: per-row bests are kept for single-pair calls only");
+        const size_t bests = (size_t)round_up(((int64_t)maxNA + maxNB) * (int64_t)sizeof(int32_t), 16);
+        SFM_HIP(ctx, res->m1.reserve(16 + bests + (size_t)std::min(maxNA, maxNB) * sizeof(int2)));
+        packed = res->m1.as<unsigned char>();
+        packedM1 = reinterpret_cast<int32_t *>(packed + 16);
+        packedM2 = packedM1 + maxNA;
+        packedPairs = reinterpret_cast<int2 *>(packed + 16 + bests);
+        res->packedBytes = 16 + bests; // up to the list
     }
     hipStream_t st = ctx->stream;
-    SFM_HIP(ctx, hipMemsetAsync(res->offsets.p, 0, sizeof(int64_t), st));
-    SFM_HIP(ctx, hipMemsetAsync(res->stats.p, 0, 4 * sizeof(u64), st));
+    if (n_pairs == 0) SFM_HIP(ctx, clear_ranges(st, {{res->offsets.p, sizeof(int64_t)}, {res->stats.p, 4 * sizeof(u64)}}));
     if (overlap) { // the second stream starts where the first one stands
         SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
@@ -1437,6 +1554,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.norms2 = set->norms2.as<float>();
     g.pts = set->pts.as<double2>();
     g.maxQueues = maxQueues;
+    g.colSplit = colSplit;
     g.blockRows = BLOCK_ROWS;
     g.wavesPerBlock = wavesPerBlock;
     g.stats = res->stats.as<u64>();
@@ -1476,16 +1594,23 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                                             hipMemcpyHostToDevice, st));
         }
         g.pairs = res->pairRecs.as<PairRec>() + c0;
+        {
+            const int nImg = set->n_images ? set->n_images : 1;
+            const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, nImg, set->dim, metric, threshold, ratio};
+            hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, st, res->pairRecs.as<PairRec>() + c0, np, b);
+        }
         const int2 *workList[2] = {res->work.as<int2>() + chunkWorkBase[0][ci], res->work.as<int2>() + chunkWorkBase[1][ci]};
         g.work = workList[0];
         g.orient = 0;
         int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
         if (overlap && ci >= (size_t)sets) { // the chunk that had this set before has written its lists and cleared it
             SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[3 + par], 0));
-        } else {
-            if (bestLen > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)bestLen * sizeof(u64), st));
-            SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)np * maxQueues * sizeof(int), st));
-            SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
+        } else { // (the first chunk also clears the first offset and the call's counters)
+            SFM_HIP(ctx, clear_ranges(st, {{bestBuf, (size_t)bestLen * sizeof(u64)},
+                                           {candCountBuf, (size_t)np * maxQueues * sizeof(int)},
+                                           {pairOvfBuf, (size_t)(chunkPairs + 4) * sizeof(int)},
+                                           {res->offsets.p, ci == 0 ? sizeof(int64_t) : 0},
+                                           {res->stats.p, ci == 0 ? 4 * sizeof(u64) : 0}}));
         }
         const int nblk = chunkWorkCount[0][ci];
         const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
@@ -1525,10 +1650,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             g.orient = 0;
             g.work = workList[0];
             const bool fast128 = set->dim == 128 && maxQueues <= 1024;
+            const int candBlocks = std::max(4, std::min(32, 2 * ctx->n_cus / np)); // blocks per pair of the exact pass
             if (candCap > 0) {
                 if (fast128)
                     hipLaunchKernelGGL((g.desc8u ? match_cand128_kernel<true, false> : match_cand128_kernel<false, false>),
-                                       dim3(4, np), dim3(256), 0, st, g);
+                                       dim3(candBlocks, np), dim3(256), 0, st, g);
                 else
                     hipLaunchKernelGGL(match_cand_kernel<false>, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
             }
@@ -1539,7 +1665,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 if (candCap > 0) {
                     if (fast128)
                         hipLaunchKernelGGL((g.desc8u ? match_cand128_kernel<true, true> : match_cand128_kernel<false, true>),
-                                           dim3(4, np), dim3(256), 0, st, g);
+                                           dim3(candBlocks, np), dim3(256), 0, st, g);
                     else
                         hipLaunchKernelGGL(match_cand_kernel<true>, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
                 }
@@ -1552,13 +1678,21 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
         }
         // (the scan continues the offsets of the chunk before: same stream, in order)
-        hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best, countsBuf,
-                           (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-        hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, countsBuf, np, res->offsets.as<int64_t>(),
-                           (int64_t)c0);
-        hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
-                           (int *)nullptr, res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(),
-                           want_m1m2 ? res->m1.as<int32_t>() : nullptr, want_m1m2 ? res->m2.as<int32_t>() : nullptr);
+        if (np == 1) { // one pair: its list starts at the offset before it, no counting pass and no scan
+            hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(1), dim3(256), 0, st, g.pairs, g.best, (int *)nullptr,
+                               res->offsets.as<int64_t>() + c0, packed ? packedPairs : res->pairs.as<int2>(),
+                               packed ? packedM1 : nullptr, packed ? packedM2 : nullptr, res->offsets.as<int64_t>() + c0,
+                               packed ? reinterpret_cast<int64_t *>(packed) : nullptr);
+        } else {
+            hipLaunchKernelGGL((match_mutual_kernel<false>), dim3(np), dim3(256), 0, st, g.pairs, g.best, countsBuf,
+                               (const int64_t *)nullptr, (int2 *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                               (int64_t *)nullptr, (int64_t *)nullptr);
+            hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, countsBuf, np, res->offsets.as<int64_t>(),
+                               (int64_t)c0);
+            hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
+                               (int *)nullptr, res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(),
+                               (int32_t *)nullptr, (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
+        }
         if (overlap && ci + sets < (size_t)nChunks) { // clear the set for the chunk that takes it next (sizes: upper bounds)
             if (maxBest > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)maxBest * sizeof(u64), st));
             SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)chunkPairs * maxQueues * sizeof(int), st));
@@ -1693,37 +1827,38 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
     const int32_t counts[2] = {nA, nB};
     const TwoParts parts = {{descA, descB}, {ptsA, ptsB}};
     sfm_imageset *set = nullptr;
-    int rc = imageset_build(ctx, 2, counts, nullptr, nullptr, dim, false, &set, nullptr, &ctx->pair_set, &parts);
+    // Nothing waits for the device between the upload and the copy of the results: the set is built without
+    // its host-side flags, and the result kept in the context is idle because every call ends with a wait.
+    int rc = imageset_build(ctx, 2, counts, nullptr, nullptr, dim, false, &set, nullptr, &ctx->pair_set, &parts, true);
     if (rc != SFM_OK) return rc;
     ctx->pair_set = set;
     const int32_t pl[2] = {0, 1};
-    rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &ctx->pair_result, true);
-    if (rc != SFM_OK) return rc;
+    rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &ctx->pair_result, true, 0.0f, true);
+    if (rc != SFM_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
     sfm_match_result *res = ctx->pair_result;
-    // The count, min(nA, nB, capacity) entries of the list (the count is not known yet) and the optional
-    // per-row / per-column bests go to one pinned buffer: one wait for the whole call.
+    // The count, the per-row / per-column bests and min(nA, nB, capacity) entries of the list (the count is not
+    // known yet) come in one copy into a pinned buffer: one wait for the whole call.
     const size_t nList = (size_t)std::min(std::min(nA, nB), capacity);
-    const size_t b1 = matches1_out ? (size_t)nA * sizeof(int32_t) : 0, b2 = matches2_out ? (size_t)nB * sizeof(int32_t) : 0;
-    SFM_HIP(ctx, res->hostOut.reserve(16 + nList * sizeof(int2) + b1 + b2));
+    const size_t bytesOut = res->packedBytes + nList * sizeof(int2);
+    SFM_HIP(ctx, res->hostOut.reserve(bytesOut));
     unsigned char *stage = res->hostOut.as<unsigned char>();
     hipStream_t st = ctx->stream;
-    SFM_HIP(ctx, hipMemcpyAsync(stage, res->offsets.as<int64_t>() + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    size_t at = 16;
-    if (nList > 0) SFM_HIP(ctx, hipMemcpyAsync(stage + at, res->pairs.p, nList * sizeof(int2), hipMemcpyDeviceToHost, st));
-    at += nList * sizeof(int2);
-    if (b1) SFM_HIP(ctx, hipMemcpyAsync(stage + at, res->m1.p, b1, hipMemcpyDeviceToHost, st));
-    if (b2) SFM_HIP(ctx, hipMemcpyAsync(stage + at + b1, res->m2.p, b2, hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipMemcpyAsync(stage, res->m1.p, bytesOut, hipMemcpyDeviceToHost, st));
     SFM_HIP(ctx, hipStreamSynchronize(st));
+    const size_t b1 = matches1_out ? (size_t)nA * sizeof(int32_t) : 0, b2 = matches2_out ? (size_t)nB * sizeof(int32_t) : 0;
     int64_t total = 0;
     memcpy(&total, stage, sizeof total);
     res->total = total;
     if (total > capacity) SFM_FAIL(ctx, SFM_ERR_CAPACITY, "match: output capacity too small");
     if (total > 0) {
         if (!pairs_out) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: null output list");
-        memcpy(pairs_out, stage + 16, (size_t)total * sizeof(int2));
+        memcpy(pairs_out, stage + res->packedBytes, (size_t)total * sizeof(int2));
     }
-    if (b1) memcpy(matches1_out, stage + at, b1);
-    if (b2) memcpy(matches2_out, stage + at + b1, b2);
+    if (b1) memcpy(matches1_out, stage + 16, b1);
+    if (b2) memcpy(matches2_out, stage + 16 + (size_t)nA * sizeof(int32_t), b2);
     *count_out = (int)total;
     return SFM_OK;
 }

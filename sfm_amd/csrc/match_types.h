@@ -12,6 +12,7 @@ struct PairRec {
     float thr_m;            // candidate bound on the approximate cosine
     int32_t thr_i;          // the same bound on the int8 dot product (instances that use the int8 table)
     int32_t chunkLocal;     // index inside the chunk
+    int32_t ia, ib;         // the two images in their set (float matcher: the bounds are made from their statistics on the device)
     int32_t pad_;
 };
 
@@ -41,7 +42,8 @@ struct MatchArgs {
     int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
     int nWork;            // entries of the work list (passes that walk it)
     int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
-    int maxQueues;        // slices per pair (row blocks * waves), upper bound over the batch
+    int maxQueues;        // slices per pair (row blocks * waves * column parts), upper bound over the batch
+    int colSplit;         // strict passes: column parts per row block (0 or 1 = a block walks all columns); work item y = row block | part << 24
     u64 *best;            // row keys and column keys of the chunk
     int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
     u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell, [2] pairs that needed the filtered passes, [3] pairs settled by the fp16 strict pass after the int8 one flooded
@@ -67,11 +69,13 @@ struct sfm_imageset {
     std::vector<ImageRec> images;
     std::vector<int> flags;
     int64_t rows32 = 0, rows16 = 0;
-    DevBuf desc32, desc16, desc8, desc8u, norms, norms2, pts, imageRecs, imageFlags, imageStats;
-    std::vector<float> scale8; // per image: int8 value = round(unit-normalised element * scale8)
-    std::vector<float> l1max;  // per image: largest L1 norm of a unit-normalised descriptor
-    std::vector<float> normMin, normMax; // per image: smallest / largest descriptor norm inside the safe range
+    DevBuf desc32, desc16, desc8, desc8u, norms, norms2, pts, imageRecs, imageStats;
+    // imageStats (device, ints holding float bit patterns): [image][2] = largest |element| and largest L1 norm of the
+    // unit-normalised descriptors (the int8 value of an element is round(element * 127 / largest)), then
+    // [image][2] = 0x7FFFFFFF - bits of the smallest norm, bits of the largest (norms inside the safe range),
+    // then [image] = IMG_* flags.
     bool owns_desc32 = true, owns_pts = true;
+    bool flags_on_host = true; // false: built without waiting for the device (single-pair calls); flags stays zero
     bool u8_exact = false;     // desc8u holds a byte copy of desc32 (every element an integer in [0, 255], dim 128)
 };
 
@@ -80,9 +84,10 @@ struct sfm_match_result {
     int n_pairs = 0;
     DevBuf offsets; // int64[n_pairs+1]
     DevBuf pairs;   // int2[sum min(nA,nB)]
-    DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, m2, kill;
+    DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, kill; // m1: packed outputs of a single-pair call
     PinBuf hostRecs, hostWork, hostOut; // hostOut: staging of the single-pair entry point's outputs
     int64_t total = -1;
+    size_t packedBytes = 0; // single-pair calls: bytes of m1 before the list (count, per-row and per-column bests)
     hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
 };
 

@@ -212,6 +212,43 @@ def test_chunks_on_two_streams_give_the_same_lists(ctx, oracle, metric, threshol
     s.close()
 
 
+@pytest.mark.parametrize("split", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("sim_variant", [1, 0])
+def test_column_parts_give_the_same_lists(ctx, oracle, split, sim_variant):
+    """Small launches of the strict passes cut each row block's columns into parts, one block per part with its
+    own slices of the candidate list.  Whatever the number of parts (also more parts than a short image has
+    steps of 64 columns, and lists so short that the later passes take over), the lists are the restatement's."""
+    counts = np.array([640, 257, 0, 1500, 64, 2100, 1], np.int32)
+    n = int(counts.max())
+    d, p, _ = synth.image_set(len(counts), n, seed=77)
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)])
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    pl = synth.exhaustive_pairs(len(counts))
+    pl = np.concatenate([pl, pl[:, ::-1]]).astype(np.int32)
+    s = ctx.imageset(counts, desc, pts)
+    ctx.set_option("match_col_split", split)
+    ctx.set_option("sim_variant", sim_variant)
+    ctx.set_option("pairs_per_launch", 16)
+    try:
+        for thr, gate, cap in ((0.95, 1e8, DEFAULT_CAND_CAPACITY), (0.5, 200.0 * 200.0, DEFAULT_CAND_CAPACITY), (0.9, 1e8, 4096)):
+            ctx.set_option("cand_capacity", cap)
+            res = s.match(pl, threshold=thr, max_dist_sq=gate)
+            off, pairs = res.offsets(), res.pairs()
+            res.close()
+            for k, (a, b) in enumerate(pl):
+                exp, _, _ = oracle.match(desc[starts[a]:starts[a + 1]], pts[starts[a]:starts[a + 1]],
+                                         desc[starts[b]:starts[b + 1]], pts[starts[b]:starts[b + 1]],
+                                         threshold=thr, max_dist_sq=gate)
+                assert np.array_equal(pairs[off[k]:off[k + 1]], exp), f"threshold {thr}: pair {k} ({a},{b})"
+    finally:
+        ctx.set_option("match_col_split", 0)
+        ctx.set_option("sim_variant", 1)
+        ctx.set_option("pairs_per_launch", 2048)
+        ctx.set_option("cand_capacity", DEFAULT_CAND_CAPACITY)
+    s.close()
+
+
 @pytest.mark.parametrize("sim_variant", [1, 0])
 @pytest.mark.parametrize("gate", [1e8, 1e4])
 def test_benchmark_pair_against_restatement(ctx, oracle, sim_variant, gate):
