@@ -18,15 +18,13 @@ namespace SfM::match
     {
         // Keypoint is an array of structures with one heap block per descriptor (SfM.hpp:125-140); the
         // library takes one contiguous descriptor table and one point table per image.
-        void pack(const std::vector<Keypoint> &kps, size_t dim, std::vector<float> &desc, std::vector<double> &pts)
+        void pack(const std::vector<Keypoint> &kps, size_t dim, float *desc, double *pts)
         {
-            desc.resize(kps.size() * dim);
-            pts.resize(kps.size() * 2);
             for (size_t i = 0; i < kps.size(); i++) {
                 if (kps[i].descriptor.size() != dim)
                     throw std::invalid_argument("Match: descriptors of different lengths (" + std::to_string(dim) + " and " +
                                                 std::to_string(kps[i].descriptor.size()) + ")");
-                std::memcpy(desc.data() + i * dim, kps[i].descriptor.data(), dim * sizeof(float));
+                std::memcpy(desc + i * dim, kps[i].descriptor.data(), dim * sizeof(float));
                 pts[2 * i] = kps[i].point[0];
                 pts[2 * i + 1] = kps[i].point[1];
             }
@@ -55,16 +53,17 @@ namespace SfM::match
         if (keypoints1.empty() || keypoints2.empty()) return result; // the reference's loops do not run
 
         const size_t dim = keypoints1[0].descriptor.size();
-        std::vector<float> descA, descB;
-        std::vector<double> ptsA, ptsB;
+        sfm_ctx *ctx = sfm_amd_adaptor::context();
+        static thread_local sfm_amd_adaptor::PinnedTable tables[4]; // packed tables stay page-locked from call to call
+        float *descA = tables[0].reserve<float>(ctx, keypoints1.size() * dim), *descB = tables[1].reserve<float>(ctx, keypoints2.size() * dim);
+        double *ptsA = tables[2].reserve<double>(ctx, keypoints1.size() * 2), *ptsB = tables[3].reserve<double>(ctx, keypoints2.size() * 2);
         pack(keypoints1, dim, descA, ptsA);
         pack(keypoints2, dim, descB, ptsB);
         const int capacity = static_cast<int>(std::min(keypoints1.size(), keypoints2.size()));
         std::vector<int32_t> pairs(2 * static_cast<size_t>(capacity));
         int count = 0;
-        sfm_ctx *ctx = sfm_amd_adaptor::context();
-        const int rc = sfm_match_pair(ctx, SFM_MATCH_TWO_SIDED, descA.data(), ptsA.data(), static_cast<int>(keypoints1.size()),
-                                      descB.data(), ptsB.data(), static_cast<int>(keypoints2.size()), static_cast<int>(dim), metric,
+        const int rc = sfm_match_pair(ctx, SFM_MATCH_TWO_SIDED, descA, ptsA, static_cast<int>(keypoints1.size()),
+                                      descB, ptsB, static_cast<int>(keypoints2.size()), static_cast<int>(dim), metric,
                                       options.threshold, options.maxDistancePxSquared, pairs.data(), capacity, &count, nullptr, nullptr);
         if (rc != SFM_OK) sfm_amd_adaptor::fail(ctx, rc, "sfm_match_pair");
         result.reserve(count);

@@ -8,6 +8,7 @@
 #include <sfm_amd.h>
 
 #include <cstdlib>
+#include <new>
 #include <stdexcept>
 #include <string>
 
@@ -32,6 +33,28 @@ namespace sfm_amd_adaptor
         }
         return holder.ctx;
     }
+
+    // Grow-only table in page-locked host memory (sfm_host_alloc): what the adaptors pack the caller's
+    // vectors into, so that the upload runs at the link's rate.  One per thread and role, kept between calls.
+    struct PinnedTable
+    {
+        void *p = nullptr;
+        size_t cap = 0;
+        ~PinnedTable() { sfm_host_free(p); }
+        template <typename T> T *reserve(sfm_ctx *ctx, size_t count)
+        {
+            const size_t bytes = count * sizeof(T);
+            if (bytes > cap) {
+                sfm_host_free(p);
+                p = nullptr;
+                cap = 0;
+                const size_t want = bytes + bytes / 4 + 4096;
+                if (sfm_host_alloc(ctx, want, &p) != SFM_OK) throw std::bad_alloc();
+                cap = want;
+            }
+            return static_cast<T *>(p);
+        }
+    };
 
     // Status codes back to the reference's conventions: invalid arguments are std::invalid_argument
     // (match.cpp:18, eightPoint.cpp:61,230), everything else std::runtime_error.

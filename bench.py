@@ -215,6 +215,7 @@ def main():
 
     total_matches = res.total()
     cand, ovf = res.stats()
+    res_bytes = res.device_bytes()
     gathered_total = None
     if rank == 0 and multi and gathered is not None:
         gathered_total = int(gathered.total()) if comm is not None else int(gathered[2].shape[0])
@@ -247,6 +248,7 @@ def main():
             "matches_rank0": int(total_matches), "candidates_rank0": int(cand), "overflow_rank0": int(ovf),
             "gather": gather_mode, "matches_gathered_on_rank0": gathered_total,
             "setup_s": round(gen_s, 2),
+            "device_bytes_rank0": {"image_set": imgset.device_bytes(), "matcher_work_buffers_and_lists": res_bytes},
         },
         "roofline": {
             "bound": "mfma", "kernel": "match_sim_kernel",
@@ -418,9 +420,9 @@ def bench_pipeline(ctx, args):
     s = ctx.imageset(counts, desc, pts)
     res = corr = batch = None
     ids = n_tracks = None
-    stage_ms = np.zeros(5)
-    reps = max(1, args.steps)
-    for it in range(reps + 1):
+    rounds = []
+    reps, warm = max(20, args.steps), 5  # a round is ~1.5 ms: the first rounds of a process run slow (clocks, runtime pools)
+    for it in range(reps + warm):
         t = [time.perf_counter()]
         res = s.match(pl, threshold=0.95, max_dist_sq=100.0 * 100.0, result=res)
         ctx.synchronize(); t.append(time.perf_counter())
@@ -436,9 +438,9 @@ def bench_pipeline(ctx, args):
             t[-1] = time.perf_counter()
         chain = batch.scale_chain(ids, n_tracks=n_tracks)
         t.append(time.perf_counter())
-        if it > 0:  # first round warms up allocations
-            stage_ms += np.diff(t) * 1e3
-    stage_ms /= reps
+        if it >= warm:
+            rounds.append(np.diff(t) * 1e3)
+    stage_ms = np.median(np.array(rounds), axis=0)  # per stage, over the timed rounds
     best = batch.best()
     total = float(stage_ms.sum())
     # The reference's own call pattern (scene.cpp:60, :261): one pair per call, host buffers in, lists out.
@@ -472,6 +474,7 @@ def bench_pipeline(ctx, args):
     ctx.set_option("ransac_seed", 0)
     out = {
         "workload": f"{frames} synthetic frames x {feats} features, {frames - 1} consecutive pairs, {H} hypotheses per pair",
+        "timing": f"median per stage over {reps} rounds after {warm} untimed ones",
         "ms": {"match": round(stage_ms[0], 3), "correspondences": round(stage_ms[1], 3),
                "ransac": round(stage_ms[2], 3), "refit": round(stage_ms[3], 3), "chain": round(stage_ms[4], 3), "total": round(total, 3)},
         "pairs_per_s": round((frames - 1) / (total * 1e-3), 1),

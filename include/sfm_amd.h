@@ -84,7 +84,12 @@ const char *sfm_version(void);
  * bound passes on a second stream of the context while the next chunk's bound
  * passes start, default; 0 = everything on one stream; results are identical;
  * either way the call's work is ordered before whatever follows it on the
- * context), "match_col_split" (0 = a matcher launch too small to fill the
+ * context), "cand_observe" (1 = a batch call of several chunks runs a first
+ * chunk of at most 128 pairs with "cand_capacity" slots per pair, looks at how
+ * far the lists filled and sizes the lists of the other chunks from that,
+ * remembering the size in the result object for later calls with the same
+ * options, default; 0 = every chunk gets "cand_capacity" slots per pair;
+ * results are identical), "match_col_split" (0 = a matcher launch too small to fill the
  * device cuts every row block's columns into 2, 4, 8 or 16 parts, one block
  * each, default; 1, 2, 4, 8, 16 = that many parts always; results are
  * identical).
@@ -203,6 +208,9 @@ int sfm_match_result_stats(sfm_match_result *res, int64_t *candidates_out, int64
  * [2] pairs that needed the filtered (row-best / column-best) passes, [3] pairs
  * whose int8 bound admitted too many cells and that the fp16 bound settled. */
 int sfm_match_result_stats_ex(sfm_match_result *res, int64_t *stats4_out);
+/* Bytes of device memory the result object holds (work buffers and lists; no
+ * counterpart in the reference). */
+int64_t sfm_match_result_device_bytes(const sfm_match_result *res);
 void sfm_match_result_destroy(sfm_match_result *res);
 
 /* ---- RANSAC: one image pair -------------------------------------------------

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_u8", "sfm_imageset_create_device", "sfm_imageset_destroy",
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
+    "sfm_match_result_device_bytes",
     "sfm_match_result_destroy",
     "sfm_ransac_pair", "sfm_ransac_pair_static", "sfm_eight_point_fit", "sfm_eight_point_from_subset", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
@@ -98,6 +99,9 @@ def lib() -> C.CDLL:
     L.sfm_match_result_device.argtypes = [vp, P(vp), P(vp)]
     L.sfm_match_result_stats.argtypes = [vp, P(i64), P(i64)]
     L.sfm_match_result_stats_ex.argtypes = [vp, vp]
+    if hasattr(L, "sfm_match_result_device_bytes"):
+        L.sfm_match_result_device_bytes.argtypes = [vp]
+        L.sfm_match_result_device_bytes.restype = i64
     L.sfm_match_result_destroy.argtypes = [vp]
     L.sfm_match_result_destroy.restype = None
     L.sfm_ransac_pair.argtypes = [vp, vp, vp, i32, vp, vp, i32, i32, f64, f64, i32, i32, vp, i32, P(i32),
@@ -667,6 +671,9 @@ class MatchResult:
         out = np.zeros(4, np.int64)
         self.ctx.check(lib().sfm_match_result_stats_ex(self._h, _ptr(out)))
         return tuple(int(v) for v in out)
+
+    def device_bytes(self):
+        return int(lib().sfm_match_result_device_bytes(self._h))
 
     def close(self):
         if self._h:

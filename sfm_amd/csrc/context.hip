@@ -107,6 +107,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->chain_table_entries = value;
     } else if (!strcmp(key, "hamming_mfma")) {
         ctx->hamming_mfma = value != 0;
+    } else if (!strcmp(key, "cand_observe")) {
+        ctx->cand_observe = value != 0;
     } else if (!strcmp(key, "match_overlap")) {
         ctx->match_overlap = value != 0;
     } else if (!strcmp(key, "match_col_split")) {

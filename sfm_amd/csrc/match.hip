@@ -1329,7 +1329,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     (void)hipStreamSynchronize(r->ctx->stream2); // a call that failed half-way may have left work of this result there
     if (r->done) (void)hipEventDestroy(r->done);
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
-                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill};
+                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe};
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
@@ -1378,7 +1378,40 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     const SimVariant &variant = kSimVariants[ctx->sim_variant];
     const int BLOCK_ROWS = SIM_BLOCK_ROWS; // <= ROW_PAD
     const int chunkPairs = (int)std::min<int64_t>(ctx->pairs_per_launch, n_pairs > 0 ? n_pairs : 1);
-    const int candCap = (int)ctx->cand_capacity;
+    const int candCapMax = (int)ctx->cand_capacity;
+    // Candidate slots per pair.  "cand_capacity" is what a pair may need at most (loose thresholds: hundreds of
+    // thousands); at a selective threshold a pair fills a fraction of a per cent of that, and three sets of lists
+    // for chunks of 2048 pairs at the maximum are 26 GB.  A call of several chunks therefore runs a short first
+    // chunk (at most 128 pairs) with the maximum, looks at how far its slices filled, and sizes the lists of all
+    // later chunks from that; the size is remembered in the result object for later calls with the same options.
+    // Pairs that then overflow take the more selective passes as they always did (same lists, more time), and the
+    // next call on the result object starts from four times the size.
+    const MatchKey key = {set, metric, threshold, maxDistSq, ratio, candCapMax, ctx->sim_variant};
+    bool probing = false;
+    if (ctx->cand_observe && candCapMax > 0 && n_pairs > chunkPairs) {
+        if (res->candObserved > 0 && memcmp(&res->observedFor, &key, sizeof key) == 0) {
+            // how the call before fared (a reused result has been waited for above)
+            u64 st4[4] = {0, 0, 0, 0};
+            if (res->stats.p) {
+                SFM_HIP(ctx, hipMemcpy(st4, res->stats.p, sizeof st4, hipMemcpyDeviceToHost));
+                if (st4[1] + st4[2] + st4[3] > 0) res->candObserved = (int)std::min<int64_t>(candCapMax, (int64_t)res->candObserved * 4);
+            }
+        } else {
+            res->candObserved = 0;
+            probing = true;
+        }
+    } else {
+        res->candObserved = 0;
+    }
+    memset(&res->observedFor, 0, sizeof res->observedFor);
+    res->observedFor = key;
+    std::vector<int> cstart; // first pair of every chunk, then n_pairs
+    for (int c0 = 0; c0 < n_pairs;) {
+        cstart.push_back(c0);
+        c0 += (probing && c0 == 0) ? std::min(chunkPairs, 128) : chunkPairs;
+    }
+    cstart.push_back(n_pairs);
+    const int nChunks = (int)cstart.size() - 1;
 
     // --- sizes ------------------------------------------------------------------------------
     // The records and work lists themselves are written chunk by chunk further down, each chunk
@@ -1398,8 +1431,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         return ((orient ? nB : nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
     };
     int64_t mostBlocks = 0; // row blocks of image A in the chunk that has most
-    for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
-        const int c1 = std::min(n_pairs, c0 + chunkPairs);
+    for (int cj = 0; cj < nChunks; cj++) {
+        const int c0 = cstart[cj], c1 = cstart[cj + 1];
         int64_t bestOff = 0, blocks = 0;
         for (int p = c0; p < c1; p++) {
             const int ia = pair_list[2 * p], ib = pair_list[2 * p + 1];
@@ -1433,8 +1466,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     // dispatch), so the row blocks that stream the same columns (one pair, one column part) are dealt to one
     // residue class mod 8 and share that XCD's L2 copy of them.
     auto residue = [&](int pairInChunk, int part) { return (pairInChunk + part) & 7; };
-    for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs) {
-        const int c1 = std::min(n_pairs, c0 + chunkPairs);
+    for (int cj = 0; cj < nChunks; cj++) {
+        const int c0 = cstart[cj], c1 = cstart[cj + 1];
         int64_t queueLen[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
         for (int p = c0; p < c1; p++) {
             const int nA = set->images[pair_list[2 * p]].n, nB = set->images[pair_list[2 * p + 1]].n;
@@ -1503,13 +1536,22 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     // soon as the chunk's lists are written, so the first stream neither clears nor, as long as the second
     // keeps up, waits.  Events: ev[0..2] a chunk's bound passes are done, ev[3..5] its set is clear again
     // (by set), ev[6] fork / join of the two streams.
-    const int nChunks = n_pairs > 0 ? (n_pairs + chunkPairs - 1) / chunkPairs : 0;
     const bool overlap = ctx->match_overlap && nChunks > 1 && !want_m1m2;
     const int sets = overlap ? std::min(3, nChunks) : 1;
-    const size_t candSet = (size_t)round_up((int64_t)((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)), 256);
-    SFM_HIP(ctx, res->cand.reserve(candSet * sets));
     const int maxQueues = std::max(1, std::max((maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS,
                                                (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS * colSplit)) * wavesPerBlock;
+    // lists: the first chunk of a call that observes has a region of its own at the maximum; the sets of the
+    // other chunks are sized once that chunk's bound passes have run (see below)
+    int candCap = res->candObserved > 0 ? std::min(res->candObserved, candCapMax) : candCapMax;
+    size_t candSet = 0;
+    auto reserve_lists = [&]() -> hipError_t {
+        candSet = (size_t)round_up((int64_t)((size_t)chunkPairs * (candCap ? candCap : 1) * sizeof(uint2)), 256);
+        return res->cand.reserve(candSet * sets);
+    };
+    if (probing)
+        SFM_HIP(ctx, res->candProbe.reserve((size_t)(cstart[1] - cstart[0]) * candCapMax * sizeof(uint2)));
+    else
+        SFM_HIP(ctx, reserve_lists());
     const size_t candCountSet = (size_t)round_up((int64_t)((size_t)chunkPairs * maxQueues * sizeof(int)), 256);
     SFM_HIP(ctx, res->candCount.reserve(candCountSet * sets));
     const size_t pairOvfSet = (size_t)round_up((int64_t)((size_t)(chunkPairs + 4) * sizeof(int)), 256); // flags, then how often each value was set
@@ -1558,17 +1600,37 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.blockRows = BLOCK_ROWS;
     g.wavesPerBlock = wavesPerBlock;
     g.stats = res->stats.as<u64>();
-    g.candCap = candCap;
     g.dim = set->dim;
     g.metric = metric;
     g.threshold = threshold;
     g.maxDistSq = maxDistSq;
     g.ratioSq = (double)ratio * (double)ratio;
 
-    size_t ci = 0;
-    for (int c0 = 0; c0 < n_pairs; c0 += chunkPairs, ci++) {
-        const int c1 = std::min(n_pairs, c0 + chunkPairs);
+    // After the bound passes of the first chunk of a call that observes: how far did its slices fill?  (The one
+    // wait of such a call.)  Sets candCap for the chunks that follow and makes their lists.
+    auto observe = [&](hipStream_t stream, int np) -> hipError_t {
+        const size_t nCount = (size_t)np * maxQueues;
+        hipError_t e = res->hostOut.reserve((nCount + np) * sizeof(int));
+        if (e != hipSuccess) return e;
+        int *seen = res->hostOut.as<int>();
+        if ((e = hipMemcpyAsync(seen, g.candCount, nCount * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(seen + nCount, g.pairOvf, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        int fullest = 0;
+        bool gaveUp = false; // a pair went to the cell-by-cell pass: the maximum was not enough for it
+        for (size_t k = 0; k < nCount; k++) fullest = std::max(fullest, seen[k]);
+        for (int k = 0; k < np; k++) gaveUp = gaveUp || seen[nCount + k] == 2;
+        int64_t slice = 64;
+        while (slice < 2 * (int64_t)fullest + 64) slice *= 2;
+        candCap = gaveUp ? candCapMax : (int)std::min<int64_t>(candCapMax, slice * maxQueues);
+        res->candObserved = candCap;
+        return reserve_lists();
+    };
+
+    for (size_t ci = 0; ci < (size_t)nChunks; ci++) {
+        const int c0 = cstart[ci], c1 = cstart[ci + 1];
         const int np = c1 - c0;
+        const bool probe = probing && ci == 0;
         prepare_chunk(c0, c1, ci);
         // this chunk's set of buffers; st = the stream of its bound passes
         const int par = (int)(ci % (size_t)sets);
@@ -1578,7 +1640,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         char *const pairOvfBuf = res->pairOvf.as<char>() + par * pairOvfSet;
         char *const killBuf = ratio > 0.0f ? res->kill.as<char>() + par * killSet : nullptr;
         int *const countsBuf = reinterpret_cast<int *>(res->counts.as<char>() + par * countsSet);
-        g.cand = reinterpret_cast<uint2 *>(res->cand.as<char>() + par * candSet);
+        g.cand = probe ? res->candProbe.as<uint2>() : reinterpret_cast<uint2 *>(res->cand.as<char>() + par * candSet);
+        g.candCap = probe ? candCapMax : candCap;
         g.candCount = reinterpret_cast<int *>(candCountBuf);
         g.pairOvf = reinterpret_cast<int *>(pairOvfBuf);
         g.flagCount = g.pairOvf + chunkPairs;
@@ -1639,6 +1702,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                                    dim3(SIM_WAVES * 64), 0, st, g);
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
             }
+            if (probe) SFM_HIP(ctx, observe(st, np));
             // The bound passes of consecutive chunks follow each other on this stream (each fills the device on
             // its own, and their timing spans stay clean); the rest of the chunk moves to the second stream.
             if (overlap) {
@@ -1672,10 +1736,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 hipLaunchKernelGGL(ratio_rows_kernel, dim3(64, np), dim3(256), 0, st, g);
                 hipLaunchKernelGGL(ratio_apply_kernel, dim3(np), dim3(256), 0, st, g);
             }
-        } else if (overlap) { // a chunk without work: its memsets still precede what follows
-            SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
-            st = ctx->stream2;
-            SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
+        } else { // a chunk without work: its memsets still precede what follows
+            if (probe) SFM_HIP(ctx, observe(st, np));
+            if (overlap) {
+                SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
+                st = ctx->stream2;
+                SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
+            }
         }
         // (the scan continues the offsets of the chunk before: same stream, in order)
         if (np == 1) { // one pair: its list starts at the offset before it, no counting pass and no scan
@@ -1869,6 +1936,16 @@ void sfm_pair_match_free(sfm_ctx *ctx)
     if (ctx->pair_set) sfm_imageset_destroy(ctx->pair_set);
     ctx->pair_result = nullptr;
     ctx->pair_set = nullptr;
+}
+
+extern "C" int64_t sfm_match_result_device_bytes(const sfm_match_result *r)
+{
+    if (!r) return 0;
+    const DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
+                            &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe};
+    int64_t total = 0;
+    for (const DevBuf *b : bufs) total += (int64_t)b->cap;
+    return total;
 }
 
 extern "C" int sfm_match_result_stats_ex(sfm_match_result *res, int64_t *stats4_out)

@@ -79,6 +79,14 @@ struct sfm_imageset {
     bool u8_exact = false;     // desc8u holds a byte copy of desc32 (every element an integer in [0, 255], dim 128)
 };
 
+// What an observed candidate-list size was observed for.
+struct MatchKey {
+    const void *set;
+    int metric;
+    float threshold, maxDistSq, ratio;
+    int capMax, simVariant;
+};
+
 struct sfm_match_result {
     sfm_ctx *ctx = nullptr;
     int n_pairs = 0;
@@ -87,6 +95,9 @@ struct sfm_match_result {
     DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, kill; // m1: packed outputs of a single-pair call
     PinBuf hostRecs, hostWork, hostOut; // hostOut: staging of the single-pair entry point's outputs
     int64_t total = -1;
+    DevBuf candProbe;        // lists of the first chunk of a call that observes how far they fill
+    int candObserved = 0;    // candidate slots per pair sized from such a first chunk (0 = none yet)
+    MatchKey observedFor = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};
     size_t packedBytes = 0; // single-pair calls: bytes of m1 before the list (count, per-row and per-column bests)
     hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
 };

@@ -212,6 +212,49 @@ def test_chunks_on_two_streams_give_the_same_lists(ctx, oracle, metric, threshol
     s.close()
 
 
+def test_lists_sized_from_the_first_chunk(ctx, oracle):
+    """A call of several chunks sizes the candidate lists of the later chunks from what the first one needed.  Here
+    the first chunk holds unrelated images (next to no candidates) and the later ones pairs of images whose rows
+    all come four times: their slices overflow the small lists, the more selective passes take over, and the lists are
+    still the restatement's; the next call on the same result object starts from larger lists.  The result object
+    holds far less memory than with lists of the maximum size."""
+    n = 768
+    d, p, _ = synth.image_set(6, n, seed=91, shared_frac=0.0)
+    desc, pts = d.copy(), p.copy()
+    quarter = desc[4 * n:4 * n + n // 4].copy()
+    for k in (4, 5):  # every row of these two images four times, and image 5 = image 4
+        for q in range(4):
+            desc[k * n + q * (n // 4):k * n + (q + 1) * (n // 4)] = quarter
+        pts[k * n:(k + 1) * n] = pts[4 * n:5 * n]
+    counts = np.full(6, n, np.int32)
+    pl = np.array([[0, 1], [2, 3], [4, 5], [5, 4], [0, 4], [4, 4]], np.int32)
+    s = ctx.imageset(counts, desc, pts)
+    ctx.set_option("pairs_per_launch", 2)
+    try:
+        sizes = {}
+        for observe in (1, 0):
+            ctx.set_option("cand_observe", observe)
+            res = None
+            for call in range(3):
+                res = s.match(pl, threshold=0.95, max_dist_sq=1e8, result=res)
+                off, pairs = res.offsets(), res.pairs()
+                for k, (a, b) in enumerate(pl):
+                    exp, _, _ = oracle.match(desc[a * n:(a + 1) * n], pts[a * n:(a + 1) * n], desc[b * n:(b + 1) * n],
+                                             pts[b * n:(b + 1) * n], threshold=0.95, max_dist_sq=1e8)
+                    assert np.array_equal(pairs[off[k]:off[k + 1]], exp), f"observe {observe}, call {call}: pair {k} ({a},{b})"
+                if call == 0:
+                    sizes[observe] = res.device_bytes()
+                    first_stats = res.stats_ex()
+            if observe:
+                assert sum(first_stats[1:]) > 0, "the small lists were meant to overflow in the first call"
+            res.close()
+        assert sizes[1] * 2 < sizes[0], sizes  # (the first chunk keeps lists of the maximum size)
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+        ctx.set_option("cand_observe", 1)
+    s.close()
+
+
 @pytest.mark.parametrize("split", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("sim_variant", [1, 0])
 def test_column_parts_give_the_same_lists(ctx, oracle, split, sim_variant):
