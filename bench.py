@@ -404,6 +404,34 @@ def bench_extensions(ctx, args):
         "dtype": "i8 signs on MFMA, popcount re-score", "matches_per_pair": round(res.total() / len(pl), 1)}}
     res.close()
     s.close()
+
+    # L2 mode: SIFT-like descriptors whose norms differ by up to 10 % (so that the L2 order is not the cosine order),
+    # mutual nearest neighbours under |a|^2 + |b|^2 - 2 a.b below 250^2, with and without the second-best test
+    from sfm_amd import synth
+    n_img = 40
+    d, p, _ = synth.image_set(n_img, n, seed=77)
+    d = np.floor(d * rng.uniform(0.9, 1.0, size=(len(d), 1)).astype(np.float32)).astype(np.float32)
+    s = ctx.imageset(np.full(n_img, n, np.int32), d, p)
+    pl = synth.exhaustive_pairs(n_img).astype(np.int32)
+    out["l2"] = {"workload": f"{n_img} images x {n} x 128-d SIFT-like descriptors with norms spread over 10 %, exhaustive pairs "
+                             f"({len(pl)}), squared distance below 250^2", "rows": []}
+    for ratio in (0.0, 0.8):
+        res = s.match(pl, threshold=250.0 ** 2, metric=capi.METRIC_L2, ratio=ratio)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = s.match(pl, threshold=250.0 ** 2, metric=capi.METRIC_L2, ratio=ratio, result=res)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ms, launches = ctx.last_kernel_ms(0)
+        st = res.stats_ex()
+        out["l2"]["rows"].append({
+            "second_best_ratio": ratio, "pairs_per_s": round(len(pl) / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+            "sim_kernel_ms": round(ms, 3), "matches_per_pair": round(res.total() / len(pl), 1),
+            "candidates_per_pair": round(st[0] / len(pl), 1), "pairs_scored_cell_by_cell": st[1],
+            "pairs_through_filtered_passes": st[2], "pairs_redone_with_fp16_bound": st[3]})
+        res.close()
+    s.close()
     return out
 
 
