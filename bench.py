@@ -103,6 +103,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     ctx = capi.Context(local_rank)
     sim_variant, bound_dtype, bound_peak = BOUNDS[args.bound]
+    if "SFM_SIM_VARIANT" in os.environ:  # the library's timing-only ablations of the similarity kernel (wrong results)
+        sim_variant = int(os.environ["SFM_SIM_VARIANT"])
     ctx.set_option("sim_variant", sim_variant)
     if "SFM_MATCH_OVERLAP" in os.environ:  # A/B switch of the matcher's two-stream chunk overlap
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))

@@ -463,6 +463,7 @@ struct WaveQueue {
     uint2 *base;
     int cap;
     int n; // wave-uniform cursor (may run past cap: then the pair is flagged)
+    int abl; // timing-only ablations (wrong results): 4 = entries are not stored, 8 = hits are not queued at all
 };
 
 __device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int j, int lane)
@@ -470,7 +471,7 @@ __device__ __forceinline__ void queue_push(WaveQueue &wq, bool take, int i, int 
     const u64 em = __builtin_amdgcn_ballot_w64(take);
     if (em == 0) return;
     const int slot = wq.n + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-    if (take && slot < wq.cap) wq.base[slot] = make_uint2((unsigned)i, (unsigned)j);
+    if (take && slot < wq.cap && !(wq.abl & 4)) wq.base[slot] = make_uint2((unsigned)i, (unsigned)j);
     wq.n += __builtin_popcountll(em);
 }
 
@@ -542,16 +543,19 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
     constexpr bool INTEGER = std::is_same<typename AccT::VT, int>::value;
     static_assert(!INTEGER || !GENERAL, "the int8 bound has a strict instance only");
     unsigned bits = 0;
+    // Strict instances: four independent chains of maxima (chain k takes accumulators 8 m + 2 k and 8 m + 2 k + 1)
+    // keep the dependent-issue latency short; no branch, so the chains can be scheduled among MFMAs.  fmaxf
+    // ignores NaNs, and a NaN cell can never be accepted.
+    typename AccT::VT m[4];
     if constexpr (INTEGER) {
-        // Four independent chains keep the dependent-issue latency short; no branch, so the chain
-        // can be scheduled among MFMAs.
-        int m[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = INT_MIN;
 #pragma unroll
         for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = max(max(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
         bits = max(max(m[0], m[1]), max(m[2], m[3])) > thr_m;
     } else if constexpr (!GENERAL) {
-        // the same in fp32; fmaxf ignores NaNs, and a NaN cell can never be accepted
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = -INFINITY;
 #pragma unroll
         for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = fmaxf(fmaxf(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
         bits = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) > thr_m;
@@ -578,9 +582,24 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
 
     bool swapped = false;
     if constexpr (!GENERAL) {
-        bits = 0;
+        // Every cell above the bound is queued.  The chain maxima say which quarter of the accumulators holds a
+        // hit (typically one: a true match); its eight are compared one by one, the lane masks tested on the
+        // scalar side, and only an accumulator with a hit somewhere in the wave pays for the queue.
+        const int rowLane = rowBase + 4 * (ln >> 4), colLane = colBase + (ln & 15);
 #pragma unroll
-        for (int idx = 0; idx < NV; idx++) bits |= (unsigned)(acc.get(idx) > thr_m) << idx;
+        for (int k = 0; k < 4; k++) {
+            if (__builtin_amdgcn_ballot_w64(m[k] > thr_m) == 0) continue;
+            if (wq.abl & 8) { wq.n += 1; continue; } // timing only
+#pragma unroll
+            for (int e = 0; e < NV / 4; e++) {
+                const int idx = (e >> 1) * 8 + 2 * k + (e & 1);
+                const bool hit = acc.get(idx) > thr_m;
+                if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
+                const int i = rowLane + ((idx & 15) >> 2) * 16 + (idx & 3), jj = colLane + (idx >> 4) * 16;
+                queue_push(wq, hit && i < pr.nA && jj < pr.nB, i, jj, lane);
+            }
+        }
+        return;
     } else {
         const float thrp = fmaxf(g.threshold, 0.0f);
         swapped = g.orient != 0;
@@ -779,6 +798,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 #pragma unroll
     for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
     WaveQueue wq;
+    wq.abl = ABL;
     wq.cap = g.candCap / nQueues;
     wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
     wq.n = 0;
@@ -870,6 +890,8 @@ static const SimVariant kSimVariants[] = {
     {match_sim_kernel<4, false, false, false, 3>, nullptr, "fp16, neither staging nor test (timing only)"},     // 3
     {match_sim_kernel<5, true, false, false, 2>, nullptr, "int8, no candidate test (timing only)"},             // 4
     {match_sim_kernel<5, true, false, false, 3>, nullptr, "int8, neither staging nor test (timing only)"},      // 5
+    {match_sim_kernel<5, true, false, false, 4>, nullptr, "int8, candidates not stored (timing only)"},         // 6
+    {match_sim_kernel<5, true, false, false, 8>, nullptr, "int8, hits not queued (timing only)"},               // 7
 };
 // cosine with the row-best filter (loose thresholds), and the dot metric: fp16 bound, two blocks per CU
 // Binary descriptors as 256 signs (+1 / -1) per row: the int32 sum is 256 - 2 * Hamming distance, exactly.
