@@ -161,11 +161,12 @@ def main():
             gather_mode = "torch (library communicator failed)"
 
     def launch(k):
-        if gathers[k & 1] is not None:
-            gathers[k & 1].wait()  # the gather that read this result object two steps ago
-        results[k & 1] = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=results[k & 1],
-                                      ratio=args.ratio)
-        return results[k & 1]
+        slot = (k & 1) if multi else 0  # two result objects only where a gather still reads the one of the step before
+        if gathers[slot] is not None:
+            gathers[slot].wait()  # the gather that read this result object two steps ago
+        results[slot] = imgset.match(my_pairs, threshold=args.threshold, max_dist_sq=1e8, result=results[slot],
+                                     ratio=args.ratio)
+        return results[slot]
 
     def gather(r, k):
         nonlocal gathered
@@ -185,17 +186,20 @@ def main():
         nonlocal res
         ms, nl = 0.0, 0
         prev = None
+        # Steps follow each other without a wait on the host: the library queues step k + 1 behind step k (and the
+        # gather of step k - 1 beside it), as a caller that streams batches would.  Only the torch stand-by for the
+        # gather needs the host between steps.
         for k in range(n_steps):
             res = launch(k)
             if multi and prev is not None:
                 gather(prev, k - 1)
-            ctx.synchronize()
             if multi and comm is None:
+                ctx.synchronize()
                 torch.cuda.synchronize()  # the gather reads prev's buffers, which step k + 1 overwrites
                 res.total()               # cached: gather() must not wait on the library's stream later
-            a, b = ctx.last_kernel_ms(0)
-            ms, nl = ms + a, nl + b
             prev = res
+        ctx.synchronize()
+        ms, nl = ctx.last_kernel_ms(0)  # summed over the steps ("span_accumulate")
         if multi and prev is not None:
             gather(prev, n_steps - 1)
             for g in gathers:
@@ -204,12 +208,18 @@ def main():
             torch.cuda.synchronize()
         return ms, nl
 
+    ctx.set_option("span_accumulate", 1)
+    if multi:  # both result objects have seen a call before the timed region (the first call on one sizes its lists)
+        launch(1)
+        ctx.synchronize()
+        ctx.last_kernel_ms(0)
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
     kernel_ms, kernel_launches = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    ctx.set_option("span_accumulate", 0)
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -93,6 +93,8 @@ const char *sfm_version(void);
  * device cuts every row block's columns into 2, 4, 8 or 16 parts, one block
  * each, default; 1, 2, 4, 8, 16 = that many parts always; results are
  * identical).
+ * "span_accumulate" (1 = sfm_ctx_last_kernel_ms sums over all batch calls
+ * since it was last read instead of the last call only; default 0).
  * Returns SFM_ERR_INVALID_ARG for an
  * unknown key or a value out of range. */
 int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value);

@@ -30,11 +30,14 @@ struct sfm_ctx {
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
     int match_col_split = 0;         // column parts per row block in the matcher's strict passes; 0 = chosen per call from the launch size
     int match_overlap = 1;           // 0: the matcher's chunks run one after the other on `stream` only
-    // Second stream of the batch matcher (what follows a chunk's bound passes), and the events that order the
-    // two: ev[0..2] a chunk's bound passes are done, ev[3..5] its buffer set is clear again (by set), ev[6]
-    // fork / join.
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // Two more streams of the batch matcher and the events that order the three.  stream2: what follows a
+    // chunk's first bound pass; stream3: the uploads of the next chunk's records and their bounds.  ev[0..2]
+    // a chunk's first bound pass is done, ev[3..5] its buffer set is clear again, ev[7..9] its records are on
+    // the device (all three by set), ev[6] fork / join.
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+#define SFM_CTX_EVENTS 10
+    hipEvent_t ev[SFM_CTX_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int span_accumulate = 0;         // 1: sfm_ctx_last_kernel_ms sums over all calls since it was last read
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)
     struct Span { hipEvent_t a, b; };

@@ -23,8 +23,9 @@ extern "C" int sfm_ctx_create(int device, sfm_ctx **ctx_out)
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; ok && k < 7; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) == hipSuccess;
+              hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < SFM_CTX_EVENTS; k++) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         sfm_ctx_destroy(c);
         return SFM_ERR_HIP;
@@ -45,8 +46,9 @@ static void ctx_teardown(sfm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     // events first: some were recorded on the streams that go next
-    for (int k = 0; k < 7; k++)
+    for (int k = 0; k < SFM_CTX_EVENTS; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     for (int w = 0; w < 2; w++)
         for (auto &s : ctx->span_pool[w]) {
@@ -55,6 +57,7 @@ static void ctx_teardown(sfm_ctx *ctx)
         }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     delete ctx;
 }
 
@@ -73,6 +76,7 @@ extern "C" void sfm_ctx_destroy(sfm_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
     // the objects the context made for its own use (each holds a reference)
     sfm_chain_scratch_free(ctx);
     sfm_pair_batch_free(ctx);
@@ -107,6 +111,9 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->chain_table_entries = value;
     } else if (!strcmp(key, "hamming_mfma")) {
         ctx->hamming_mfma = value != 0;
+    } else if (!strcmp(key, "span_accumulate")) {
+        ctx->span_accumulate = value != 0;
+        ctx->span_used[0] = ctx->span_used[1] = 0;
     } else if (!strcmp(key, "cand_observe")) {
         ctx->cand_observe = value != 0;
     } else if (!strcmp(key, "match_overlap")) {
@@ -134,7 +141,10 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     return SFM_OK;
 }
 
-void sfm_span_reset(sfm_ctx *ctx, int which) { ctx->span_used[which] = 0; }
+void sfm_span_reset(sfm_ctx *ctx, int which)
+{
+    if (!ctx->span_accumulate) ctx->span_used[which] = 0;
+}
 
 hipError_t sfm_span_begin(sfm_ctx *ctx, int which, hipStream_t st)
 {
@@ -166,6 +176,7 @@ extern "C" int sfm_ctx_last_kernel_ms(sfm_ctx *ctx, int which, double *ms_out, i
     }
     if (ms_out) *ms_out = total;
     if (launches_out) *launches_out = (int)ctx->span_used[which];
+    if (ctx->span_accumulate) ctx->span_used[which] = 0; // read: the next calls start a new sum
     return SFM_OK;
 }
 

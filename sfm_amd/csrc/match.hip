@@ -1349,7 +1349,11 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     (void)hipStreamSynchronize(r->ctx->stream2); // a call that failed half-way may have left work of this result there
+    (void)hipStreamSynchronize(r->ctx->stream3);
     if (r->done) (void)hipEventDestroy(r->done);
+    if (r->upDone) (void)hipEventDestroy(r->upDone);
+    if (r->statsEv) (void)hipEventDestroy(r->statsEv);
+    r->hostStats.release();
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
                       &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe};
     for (DevBuf *b : bufs) b->release();
@@ -1388,11 +1392,19 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     } else if (res->ctx != ctx) {
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: result belongs to another context");
     } else if (!result_idle) {
-        // the staging buffers of a reused result may still be the source of copies in flight (on the second
-        // stream too, when an earlier call failed between its fork and its join)
-        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        // The pinned staging buffers of a reused result may still be the source of copies in flight: wait for the
+        // uploads of the call before (not for the call itself: its kernels may still be running while this call is
+        // prepared and queued behind it; everything that touches the result's device buffers is ordered on the
+        // context's streams).  A call that failed half-way left no such marker: wait for the streams.
+        if (res->upDone && res->upValid) {
+            SFM_HIP(ctx, hipEventSynchronize(res->upDone));
+        } else {
+            SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            SFM_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+            SFM_HIP(ctx, hipStreamSynchronize(ctx->stream3));
+        }
     }
+    res->upValid = false;
     res->n_pairs = n_pairs;
     res->total = -1;
     sfm_span_reset(ctx, 0);
@@ -1412,11 +1424,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     bool probing = false;
     if (ctx->cand_observe && candCapMax > 0 && n_pairs > chunkPairs) {
         if (res->candObserved > 0 && memcmp(&res->observedFor, &key, sizeof key) == 0) {
-            // how the call before fared (a reused result has been waited for above)
-            u64 st4[4] = {0, 0, 0, 0};
-            if (res->stats.p) {
-                SFM_HIP(ctx, hipMemcpy(st4, res->stats.p, sizeof st4, hipMemcpyDeviceToHost));
+            // how the last call fared whose counters have arrived (they are fetched at the end of every call,
+            // and nobody waits for them)
+            if (res->statsEv && res->statsPending && hipEventQuery(res->statsEv) == hipSuccess) {
+                const u64 *st4 = res->hostStats.as<u64>();
                 if (st4[1] + st4[2] + st4[3] > 0) res->candObserved = (int)std::min<int64_t>(candCapMax, (int64_t)res->candObserved * 4);
+                res->statsPending = false;
             }
         } else {
             res->candObserved = 0;
@@ -1604,9 +1617,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     }
     hipStream_t st = ctx->stream;
     if (n_pairs == 0) SFM_HIP(ctx, clear_ranges(st, {{res->offsets.p, sizeof(int64_t)}, {res->stats.p, 4 * sizeof(u64)}}));
-    if (overlap) { // the second stream starts where the first one stands
+    if (overlap) { // the other two streams start where the first one stands
         SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev[6], 0));
     }
 
     MatchArgs g;
@@ -1649,14 +1663,36 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         return reserve_lists();
     };
 
+    // A chunk's records and work lists go up, and its bounds are made, one chunk ahead on a stream of their own,
+    // so that nothing but the launch itself lies between two bound passes on the context's stream.
+    const hipStream_t up = overlap ? ctx->stream3 : ctx->stream;
+    auto upload = [&](size_t ci) -> int {
+        const int c0 = cstart[ci], c1 = cstart[ci + 1], np = c1 - c0;
+        prepare_chunk(c0, c1, ci);
+        SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.as<PairRec>() + c0, recs + c0, (size_t)np * sizeof(PairRec),
+                                    hipMemcpyHostToDevice, up));
+        const int64_t w0 = chunkWorkBase[0][ci], wn = (int64_t)chunkWorkCount[0][ci] + chunkWorkCount[1][ci];
+        if (wn > 0)
+            SFM_HIP(ctx, hipMemcpyAsync(res->work.as<int2>() + w0, work + w0, (size_t)wn * sizeof(int2), hipMemcpyHostToDevice, up));
+        const int nImg = set->n_images ? set->n_images : 1;
+        const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, nImg, set->dim, metric, threshold, ratio};
+        hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, up, res->pairRecs.as<PairRec>() + c0, np, b);
+        if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[7 + (int)(ci % (size_t)sets)], up));
+        return SFM_OK;
+    };
+    if (nChunks > 0) {
+        const int rc = upload(0);
+        if (rc != SFM_OK) return rc;
+    }
+
     for (size_t ci = 0; ci < (size_t)nChunks; ci++) {
         const int c0 = cstart[ci], c1 = cstart[ci + 1];
         const int np = c1 - c0;
         const bool probe = probing && ci == 0;
-        prepare_chunk(c0, c1, ci);
         // this chunk's set of buffers; st = the stream of its bound passes
         const int par = (int)(ci % (size_t)sets);
         st = ctx->stream;
+        if (overlap) SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[7 + par], 0)); // its records are on the device
         char *const bestBuf = res->best.as<char>() + par * bestSet;
         char *const candCountBuf = res->candCount.as<char>() + par * candCountSet;
         char *const pairOvfBuf = res->pairOvf.as<char>() + par * pairOvfSet;
@@ -1670,20 +1706,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         g.best = reinterpret_cast<u64 *>(bestBuf);
         g.ovfList = reinterpret_cast<int *>(res->ovfList.as<char>() + par * ovfListSet);
         g.kill = reinterpret_cast<int *>(killBuf);
-        SFM_HIP(ctx, hipMemcpyAsync(res->pairRecs.as<PairRec>() + c0, recs + c0, (size_t)np * sizeof(PairRec),
-                                    hipMemcpyHostToDevice, st));
-        {
-            const int64_t w0 = chunkWorkBase[0][ci], wn = (int64_t)chunkWorkCount[0][ci] + chunkWorkCount[1][ci];
-            if (wn > 0)
-                SFM_HIP(ctx, hipMemcpyAsync(res->work.as<int2>() + w0, work + w0, (size_t)wn * sizeof(int2),
-                                            hipMemcpyHostToDevice, st));
-        }
         g.pairs = res->pairRecs.as<PairRec>() + c0;
-        {
-            const int nImg = set->n_images ? set->n_images : 1;
-            const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, nImg, set->dim, metric, threshold, ratio};
-            hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, st, res->pairRecs.as<PairRec>() + c0, np, b);
-        }
         const int2 *workList[2] = {res->work.as<int2>() + chunkWorkBase[0][ci], res->work.as<int2>() + chunkWorkBase[1][ci]};
         g.work = workList[0];
         g.orient = 0;
@@ -1701,11 +1724,26 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
         if (nblk > 0) {
             const bool cosine = metric != SFM_METRIC_DOT; // the L2 mode runs the cosine bound passes with its own per-pair bound
+            bool forked = false;
             if (cosine) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
                 hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
                 SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
+                // The first bound passes of consecutive chunks follow each other on this stream (each fills the
+                // device on its own, and their timing spans stay clean); everything else of the chunk, the passes
+                // that redo flagged pairs included, moves to the second stream.  (The chunk that observes how far
+                // its lists fill stays on this stream until that is known.)
+                if (overlap && !probe) {
+                    SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
+                    st = ctx->stream2;
+                    SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
+                    forked = true;
+                }
+            }
+            if (ci + 1 < (size_t)nChunks) { // while the device runs this chunk, the host prepares the next
+                const int rc = upload(ci + 1);
+                if (rc != SFM_OK) return rc;
             }
             if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 g.onlyFlagged = 3;
@@ -1725,9 +1763,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
             }
             if (probe) SFM_HIP(ctx, observe(st, np));
-            // The bound passes of consecutive chunks follow each other on this stream (each fills the device on
-            // its own, and their timing spans stay clean); the rest of the chunk moves to the second stream.
-            if (overlap) {
+            if (overlap && !forked) {
                 SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
                 st = ctx->stream2;
                 SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
@@ -1759,6 +1795,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 hipLaunchKernelGGL(ratio_apply_kernel, dim3(np), dim3(256), 0, st, g);
             }
         } else { // a chunk without work: its memsets still precede what follows
+            if (ci + 1 < (size_t)nChunks) {
+                const int rc = upload(ci + 1);
+                if (rc != SFM_OK) return rc;
+            }
             if (probe) SFM_HIP(ctx, observe(st, np));
             if (overlap) {
                 SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
@@ -1793,6 +1833,17 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     if (overlap) { // the caller's stream continues once both are done
         SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream2));
         SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[6], 0));
+    }
+    // for the next call on this result object: when its staging buffers are free again, and how this call fared
+    if (!res->upDone) SFM_HIP(ctx, hipEventCreateWithFlags(&res->upDone, hipEventDisableTiming));
+    SFM_HIP(ctx, hipEventRecord(res->upDone, up));
+    res->upValid = true;
+    if (n_pairs > 0 && !want_m1m2) {
+        if (!res->statsEv) SFM_HIP(ctx, hipEventCreateWithFlags(&res->statsEv, hipEventDisableTiming));
+        SFM_HIP(ctx, res->hostStats.reserve(4 * sizeof(u64)));
+        SFM_HIP(ctx, hipMemcpyAsync(res->hostStats.p, res->stats.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipEventRecord(res->statsEv, ctx->stream));
+        res->statsPending = true;
     }
     return SFM_OK;
 }

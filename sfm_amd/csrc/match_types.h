@@ -99,6 +99,11 @@ struct sfm_match_result {
     int candObserved = 0;    // candidate slots per pair sized from such a first chunk (0 = none yet)
     MatchKey observedFor = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};
     size_t packedBytes = 0; // single-pair calls: bytes of m1 before the list (count, per-row and per-column bests)
+    hipEvent_t upDone = nullptr;  // the last upload of the last batch call from hostRecs / hostWork has been made
+    bool upValid = false;         // ... and that call ran to its end
+    hipEvent_t statsEv = nullptr; // the counters of the last batch call have arrived in hostStats
+    bool statsPending = false;
+    PinBuf hostStats;
     hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
 };
 
