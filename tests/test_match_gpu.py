@@ -423,3 +423,59 @@ def test_repeated_pair_calls_reuse_their_buffers(ctx, oracle):
     A = rng.integers(1, 200, size=(64, 128)).astype(np.float32)
     got = ctx.match_pair(A, np.zeros((64, 2)), A, np.zeros((64, 2)), threshold=0.9)  # the call after a refused one
     assert got.tolist() == [[i, i] for i in range(64)]
+
+
+def test_calls_queue_behind_each_other_without_a_wait(ctx, oracle):
+    """Batch calls return before their work is done, and a further call on the same result object waits only for
+    the uploads of the one before.  Calls with different pair lists and thresholds, issued back to back into one
+    and into two result objects, each leave the lists of the last call made on the object."""
+    counts = np.array([900, 640, 257, 1100, 64, 511], np.int32)
+    n = int(counts.max())
+    d, p, _ = synth.image_set(len(counts), n, seed=321)
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)])
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    pl_a = synth.exhaustive_pairs(len(counts)).astype(np.int32)
+    pl_b = pl_a[::-1, ::-1].copy()[:11]
+    s = ctx.imageset(counts, desc, pts)
+
+    def expect(pl, thr, gate):
+        return [oracle.match(desc[starts[a]:starts[a + 1]], pts[starts[a]:starts[a + 1]], desc[starts[b]:starts[b + 1]],
+                             pts[starts[b]:starts[b + 1]], threshold=thr, max_dist_sq=gate)[0] for a, b in pl]
+
+    def check(res, pl, want):
+        off, pairs = res.offsets(), res.pairs()
+        assert len(off) == len(pl) + 1
+        for k in range(len(pl)):
+            assert np.array_equal(pairs[off[k]:off[k + 1]], want[k]), k
+
+    want_a, want_b = expect(pl_a, 0.95, 1e8), expect(pl_b, 0.9, 150.0 ** 2)
+    ctx.set_option("pairs_per_launch", 4)  # several chunks: three streams, three buffer sets
+    try:
+        r1 = r2 = None
+        for _ in range(4):
+            r1 = s.match(pl_a, threshold=0.95, max_dist_sq=1e8, result=r1)
+            r2 = s.match(pl_b, threshold=0.9, max_dist_sq=150.0 ** 2, result=r2)
+            r1 = s.match(pl_b, threshold=0.9, max_dist_sq=150.0 ** 2, result=r1)
+            r1 = s.match(pl_a, threshold=0.95, max_dist_sq=1e8, result=r1)
+        check(r2, pl_b, want_b)
+        check(r1, pl_a, want_a)
+        r1 = s.match(pl_b, threshold=0.9, max_dist_sq=150.0 ** 2, result=r1)
+        check(r1, pl_b, want_b)
+        r1.close()
+        r2.close()
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+    s.close()
+
+
+def test_tables_in_page_locked_memory(ctx, oracle):
+    """sfm_host_alloc: tables kept in page-locked memory go through the same entry point and give the same lists."""
+    dA, pA, dB, pB = two_images(700, 900)
+    exp, e1, e2 = oracle.match(dA, pA, dB, pB, threshold=0.95, max_dist_sq=1e8)
+    tabs = [ctx.pinned_like(a) for a in (dA, pA, dB, pB)]
+    assert all(np.array_equal(t, a) for t, a in zip(tabs, (dA, pA, dB, pB)))
+    for _ in range(3):
+        got, g1, g2 = ctx.match_pair(*tabs, threshold=0.95, max_dist_sq=1e8, return_best=True)
+        assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2)
+    del tabs
