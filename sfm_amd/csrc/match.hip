@@ -8,14 +8,16 @@
 // choice is mutual.
 //
 // How: the N x M similarity matrix is never stored.
-//   1. ingest (once per image set): per descriptor the fp32 squared norm in the reference's
-//      summation order and its sqrtf; an fp16 copy of the descriptor divided by that norm.
-//   2. match_sim_kernel: fp16 MFMA over LDS-staged tiles gives an approximation of the cosine
-//      of every cell, good to 1.0e-3 absolute.  A cell whose approximation clears
-//      max(threshold, 0) - 1.5e-3 is a *candidate*; its (i, j) goes to the pair's candidate
-//      list.  Nothing else leaves the kernel.  Pairs with more candidates than the list holds
-//      are redone with a filter that keeps only cells that can be a row or column best, and
-//      as a last resort scored cell by cell.
+//   1. ingest (once per image set, ingest_rows_kernel / ingest_i8_kernel): per descriptor the fp32 squared norm in
+//      the reference's summation order and its sqrtf; an fp16 copy and an int8 copy (one scale per image) of the
+//      descriptor divided by that norm; per image the statistics the bounds below are made from.  They stay on
+//      the device: pair_bounds_kernel turns them into each pair's bounds when a batch is launched.
+//   2. match_sim_kernel bounds every cell on the matrix cores: int8 MFMA (exact int32 sums of the quantised
+//      descriptors, with a rigorous bound on the quantisation error) or fp16 MFMA (good to 1.0e-3 absolute).  A
+//      cell whose bound clears the threshold is a *candidate*; its (i, j) goes to the pair's candidate list.
+//      Nothing else leaves the kernel.  Pairs with more candidates than the list holds are redone with the tighter
+//      fp16 bound, then with a filter that keeps only cells that can be a row or column best, and as a last
+//      resort scored cell by cell.  Small launches cut each row block's columns into parts (one block each).
 //   3. match_cand128_kernel / match_cand_kernel: every candidate is re-evaluated exactly as the reference does it
 //      (128 sequential fp32 multiply-adds without contraction, IEEE sqrt/divide, fp64 pixel
 //      gate) and folded into per-row / per-column 64-bit keys (sim bits : ~index) with
@@ -24,6 +26,9 @@
 // Since every cell that the reference could accept is a candidate, and candidates are
 // scored with the reference's own arithmetic, the result is bit-identical to the
 // reference's for any finite input, not only for integer-valued SIFT descriptors.
+// A batch call runs in chunks of pairs on three streams of the context (first bound pass / everything after it /
+// uploads of the next chunk), sizes the candidate lists of later chunks from what its first chunk needed, and
+// returns before its work is done.
 #include "match_types.h"
 
 #include <initializer_list>
