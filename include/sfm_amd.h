@@ -84,7 +84,12 @@ const char *sfm_version(void);
  * bound passes on a second stream of the context while the next chunk's bound
  * passes start, default; 0 = everything on one stream; results are identical;
  * either way the call's work is ordered before whatever follows it on the
- * context), "cand_observe" (1 = a batch call of several chunks runs a first
+ * context), "match_two_phase" (1 = pairs whose candidate lists overflow and whose
+ * pixel gate excludes nothing are redone with two cheap sweeps per
+ * orientation, row maxima first and a strict sweep against them second,
+ * default; 0 = they take the filtered sweep with running row bounds like the
+ * pairs with an effective gate; results are identical),
+ * "cand_observe" (1 = a batch call of several chunks runs a first
  * chunk of at most 128 pairs with "cand_capacity" slots per pair, looks at how
  * far the lists filled and sizes the lists of the other chunks from that,
  * remembering the size in the result object for later calls with the same

@@ -114,6 +114,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "span_accumulate")) {
         ctx->span_accumulate = value != 0;
         ctx->span_used[0] = ctx->span_used[1] = 0;
+    } else if (!strcmp(key, "match_two_phase")) {
+        ctx->match_two_phase = value != 0;
     } else if (!strcmp(key, "cand_observe")) {
         ctx->cand_observe = value != 0;
     } else if (!strcmp(key, "match_overlap")) {

@@ -50,6 +50,7 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 #define IMG_WILD_COS 1 // a descriptor norm outside [1e-12, 1e12] (and not 0/inf/nan)
 #define IMG_WILD_DOT 2 // a descriptor norm that is 0, non-finite or outside that range
 #define IMG_NOT_U8 4   // an element that is not an integer in [0, 255]
+#define IMG_PTS_WILD 8 // a keypoint position that is not finite
 
 
 // ---------------------------------------------------------------------------------------
@@ -72,11 +73,32 @@ __device__ __forceinline__ int wave_max(int v)
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
     return v;
 }
+// Monotone map float -> unsigned (larger float, larger key); key 0 is below every float.
+__device__ __forceinline__ unsigned ordered_key(float v)
+{
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ __forceinline__ unsigned wave_max_u(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+// bbox[4 * image ..]: ordered keys of max x, max -x, max y, max -y over the image's points (as floats, which is
+// what the pixel gate's "can it exclude anything at all" test needs); an image with a point that is not finite
+// gets IMG_PTS_WILD instead.
 template <bool VEC>
 __global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
                                                          int dim, float *__restrict__ norms, float *__restrict__ norms2,
                                                          int *__restrict__ imageFlags, int *__restrict__ stats,
-                                                         int *__restrict__ normRange, _Float16 *__restrict__ desc16)
+                                                         int *__restrict__ normRange, _Float16 *__restrict__ desc16,
+                                                         const double2 *__restrict__ pts, unsigned *__restrict__ bbox)
 {
     const ImageRec im = images[blockIdx.y];
     const int r = blockIdx.x * 64 + threadIdx.x;
@@ -122,10 +144,20 @@ __global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict
         if (valid) *reinterpret_cast<half8 *>(out + k0) = h;
     }
     int f = 0;
+    unsigned bx[4] = {0, 0, 0, 0};
+    if (valid) {
+        const double2 pt = pts[im.row32 + r];
+        const float px = (float)pt.x, py = (float)pt.y;
+        if (fabsf(px) <= 3.0e38f && fabsf(py) <= 3.0e38f) { // (false for NaN too)
+            bx[0] = ordered_key(px), bx[1] = ordered_key(-px), bx[2] = ordered_key(py), bx[3] = ordered_key(-py);
+        } else {
+            f |= IMG_PTS_WILD;
+        }
+    }
     if (valid) {
         norms[im.row32 + r] = s;
         norms2[im.row32 + r] = normA; // the squared norm as the reference's loop accumulates it (L2 mode)
-        f = bytes ? 0 : IMG_NOT_U8;
+        f |= bytes ? 0 : IMG_NOT_U8;
         if (!ok) {
             f |= IMG_WILD_DOT;
             if (s != 0.0f && s == s && s != INFINITY) f |= IMG_WILD_COS;
@@ -139,7 +171,12 @@ __global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict
     int wF = f;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wF |= __shfl_xor(wF, d, 64);
+#pragma unroll
+    for (int e = 0; e < 4; e++) bx[e] = wave_max_u(bx[e]);
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (bx[e]) atomicMax(&bbox[4 * blockIdx.y + e], bx[e]);
         if (wMx) atomicMax(&stats[2 * blockIdx.y], wMx);
         if (wL1) atomicMax(&stats[2 * blockIdx.y + 1], wL1);
         if (wLo) atomicMax(&normRange[2 * blockIdx.y], wLo);
@@ -259,11 +296,13 @@ __global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRe
 struct BoundArgs {
     const int *stats; // [n][2] largest |element| and L1 norm, then [n][2] norm range (bit patterns, see sfm_imageset)
     const int *flags; // [n] IMG_*
+    const unsigned *bbox; // [n][4] ordered keys of max x, max -x, max y, max -y
     int nImages;
     int dim;
     int metric;
     float threshold;
     float ratio;
+    float maxDistSq;
 };
 __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ pairs, int nPairs, const BoundArgs b)
 {
@@ -322,6 +361,20 @@ __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ 
         thr_i = (int)floor(t < 2.0e9 ? t : 2.0e9);
     pairs[p].thr_m = thr_m;
     pairs[p].thr_i = thr_i;
+    // Can the pixel gate (match.cpp:45) exclude any cell of this pair?  Not if the two images' points together
+    // span less than the gate (the default, 10000^2, on any image below 7000 x 7000).
+    bool gateOff = ((b.flags[ia] | b.flags[ib]) & IMG_PTS_WILD) == 0;
+    double ext2 = 0.0;
+#pragma unroll
+    for (int axis = 0; axis < 2; axis++) {
+        const unsigned hiA = b.bbox[4 * ia + 2 * axis], loA = b.bbox[4 * ia + 2 * axis + 1];
+        const unsigned hiB = b.bbox[4 * ib + 2 * axis], loB = b.bbox[4 * ib + 2 * axis + 1];
+        if (hiA == 0 || hiB == 0 || loA == 0 || loB == 0) gateOff = false; // an image without points
+        const double hi = (double)ordered_value(max(hiA, hiB)), lo = -(double)ordered_value(max(loA, loB));
+        ext2 += (hi - lo) * (hi - lo);
+    }
+    gateOff = gateOff && (double)b.maxDistSq > ext2 * 1.0001 + 1e-3; // (the points were rounded to float: 6e-8 relative)
+    pairs[p].gateOff = gateOff ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -418,17 +471,6 @@ __device__ __forceinline__ float exact_dot(const MatchArgs &g, const PairRec &pr
     float dot = 0.0f;
     for (int k = 0; k < g.dim; k++) dot = __fadd_rn(dot, __fmul_rn(a[k], b[k]));
     return dot;
-}
-
-// Monotone map float -> unsigned (larger float, larger key); key 0 is below every float.
-__device__ __forceinline__ unsigned ordered_key(float v)
-{
-    const unsigned b = __float_as_uint(v);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ordered_value(unsigned k)
-{
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
 // A zero the optimiser cannot see through.  Index arithmetic of the rare candidate path is
@@ -539,7 +581,9 @@ struct GeneralLds {
 // serial order.  localLo[idx] is a per-lane copy of the row's bound minus the margin, in
 // registers, so that most cells are rejected by a register compare; it only ever trails the
 // shared bound, which keeps the test permissive.
-template <typename AccT, bool DOT, bool GENERAL>
+// SWAP (strict instances that run with either image in the register-resident role): rows are image B's when
+// g.orient is set, and the pairs go out as (row of A, row of B) all the same.
+template <typename AccT, bool DOT, bool GENERAL, bool SWAP = false>
 __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
                                              int colBase, int lane, typename AccT::VT thr_m, WaveQueue &wq,
                                              float (&localLo)[GENERAL ? AccT::NV : 1], const GeneralLds &gl)
@@ -601,7 +645,8 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
                 const bool hit = acc.get(idx) > thr_m;
                 if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
                 const int i = rowLane + ((idx & 15) >> 2) * 16 + (idx & 3), jj = colLane + (idx >> 4) * 16;
-                queue_push(wq, hit && i < pr.nA && jj < pr.nB, i, jj, lane);
+                const bool sw = SWAP && g.orient != 0;
+                queue_push(wq, hit && i < pr.nA && jj < pr.nB, sw ? jj : i, sw ? i : jj, lane);
             }
         }
         return;
@@ -682,9 +727,18 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // OCC = blocks per CU the register budget is set for.  FORM selects the arithmetic (the int8 forms have strict instances only).
 // ABL: timing-only ablations with wrong results: bit 0 = no staging and no barrier, bit 1 = no
 // candidate test.
-template <int FORM, bool DOT, bool GENERAL, int ABL>
+// MODE (fp16 strict instances only): the two-phase form of the filtered passes, for pairs whose pixel gate
+// excludes nothing.  A row's best cell is then its best over all columns, so
+//   1 = a sweep that only records every row's largest approximate cosine (no candidates), and
+//   2 = a strict sweep whose accumulators start at minus the row's bar, max(that maximum - 2 margins, the
+//       pair's bound): what stays positive is within reach of the row's best and is queued.
+// Both run once with each image in the register-resident role, like the filtered pass they replace, which
+// has to carry running bounds and pixel positions along and queues the harmonic number of cells per row.
+template <int FORM, bool DOT, bool GENERAL, int ABL, int MODE = 0>
 __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem)
 {
+    static_assert(MODE == 0 || (FORM == 0 && !DOT && !GENERAL), "the two-phase sweeps are fp16 strict instances");
+    constexpr bool TWOSIDED = GENERAL || MODE != 0; // runs in both orientations, slices of both in the pair's list
     // FORM 0: fp16 rows of 256 B; 1: int8 rows of 128 B; 2: int8 rows of 256 B (256 signs of a binary descriptor)
     constexpr bool I8 = FORM != 0;       // int8 MFMA, int32 sums
     constexpr bool WIDE = FORM != 1;     // 256-byte rows: the fp16 table's layout in memory and in LDS
@@ -703,17 +757,18 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     if (w.x < 0) return;
     if (g.onlyFlagged && g.pairOvf[w.x] != g.onlyFlagged) return; // later passes: pairs an earlier pass gave up on
     PairRec pr = g.pairs[w.x];
+    if (g.gateMode && (g.gateMode == 1) != (pr.gateOff != 0)) return; // the other form of the filtered passes takes this pair
     // Small launches of the strict passes cut the columns into parts, one block per (row block, part): a pair
     // of 8192 x 8192 is 32 row blocks, far too few for 256 CUs.  The filtered passes need all columns of a row
     // in one wave, in order: they take the items of part 0 and walk every column.
-    const int colParts = GENERAL ? 1 : max(g.colSplit, 1);
+    const int colParts = TWOSIDED ? 1 : max(g.colSplit, 1);
     const int colPart = w.y >> 24, rowBlock = w.y & 0xFFFFFF;
-    if (GENERAL && colPart != 0) return;
+    if (TWOSIDED && colPart != 0) return;
     // slices of the pair's candidate list: one per wave (and column part) of a strict pass, or one per wave
     // of both orientations of the general pass
     const int nQ0 = ((pr.nA + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
     const int nQ1 = ((pr.nB + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
-    if (GENERAL && g.orient) { // image B's rows stay in registers, image A streams
+    if (TWOSIDED && g.orient) { // image B's rows stay in registers, image A streams
         const int n = pr.nA; pr.nA = pr.nB; pr.nB = n;
         int64_t t = pr.rowA32; pr.rowA32 = pr.rowB32; pr.rowB32 = t;
         t = pr.rowA16; pr.rowA16 = pr.rowB16; pr.rowB16 = t;
@@ -775,9 +830,46 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         }
     }
     using AccT = typename std::conditional<I8, SimAcc<int4v, int>, SimAcc<float4v, float>>::type;
+    // Two-phase sweeps: per lane its 16 rows (row tile t, register q: row 16 t + 4 (lane >> 4) + q of the wave).
+    // MODE 1 keeps their running maxima; MODE 2 starts every accumulator at minus the row's bar.
+    float rowVal[MODE != 0 ? 4 : 1][4];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) rowVal[t][q] = -INFINITY;
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = rowBase + 16 * t + 4 * (lane >> 4) + q;
+                // The row's best exact cosine is within one margin of its approximation, which is therefore at
+                // least the largest approximation minus two margins; 1e-5 more pays for the rounding of the
+                // accumulators (they start at the bar instead of zero).  A row without a finite maximum (NaNs
+                // only) gets no bar, a row beyond the image queues nothing.
+                float bar = INFINITY;
+                if (i < pr.nA) {
+                    const float mx = g.rowMax[pr.bestRow + i];
+                    bar = fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
+                    if (!(mx == mx)) bar = pr.thr_m;
+                }
+                rowVal[t][q] = -bar;
+            }
+    }
     // one 32-column step: column tile ct, k-block s: one B fragment from LDS feeds four MFMAs
     auto mfma_step = [&](AccT &acc, int buf, int sub) __attribute__((always_inline)) {
-        acc.zero();
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc.a[c][t][q] = rowVal[t][q];
+        } else {
+            acc.zero();
+        }
 #pragma unroll
         for (int ct = 0; ct < 2; ct++)
 #pragma unroll
@@ -797,8 +889,8 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             }
     };
     // this wave's slice of the pair's candidate list
-    const int nQueues = GENERAL ? nQ0 + nQ1 : nQ0 * colParts;
-    const int queueId = ((GENERAL && g.orient) ? nQ0 : colPart * nQ0) + rowBlock * SIM_WAVES + wave;
+    const int nQueues = TWOSIDED ? nQ0 + nQ1 : nQ0 * colParts;
+    const int queueId = ((TWOSIDED && g.orient) ? nQ0 : colPart * nQ0) + rowBlock * SIM_WAVES + wave;
     float localLo[GENERAL ? AccT::NV : 1];
 #pragma unroll
     for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
@@ -807,11 +899,18 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     wq.cap = g.candCap / nQueues;
     wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
     wq.n = 0;
+    if (MODE == 2 && !(thr_m > -INFINITY)) wq.n = wq.cap + 1; // norms out of range: no bound holds, the pair is scored cell by cell
     auto test = [&](const AccT &acc, int colBase, int buf) __attribute__((always_inline)) {
         if constexpr ((ABL & 2) != 0)
             acc.keep_alive();
-        else
-            sim_epilogue<AccT, DOT, GENERAL>(g, pr, acc, rowBase, colBase, lane, typename AccT::VT(I8 ? thr_i : thr_m), wq, localLo,
+        else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) rowVal[t][q] = fmaxf(fmaxf(rowVal[t][q], acc.a[0][t][q]), acc.a[1][t][q]);
+        } else
+            sim_epilogue<AccT, DOT, GENERAL, MODE == 2>(g, pr, acc, rowBase, colBase, lane,
+                                             typename AccT::VT(I8 ? thr_i : (MODE == 2 ? 0.0f : thr_m)), wq, localLo,
                                              GeneralLds{ptsRow + (GENERAL ? wave * SIM_WAVE_ROWS : 0),
                                                         &ptsCol[GENERAL ? buf : 0][GENERAL ? (colBase % SIM_BN) : 0],
                                                         rowBound + (GENERAL ? wave * SIM_WAVE_ROWS : 0)});
@@ -850,12 +949,26 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         step(c, 0);
         if (c + 1 < nChunks) step(c + 1, (ABL & 1) ? 0 : 1);
     }
+    if constexpr (MODE == 1) {
+        // the 16 lanes that share lane >> 4 hold the same rows for 16 different columns of every tile
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float v = rowVal[t][q];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+                const int i = rowBase + 16 * t + 4 * (lane >> 4) + q;
+                if ((lane & 15) == 0 && i < pr.nA) g.rowMax[pr.bestRow + i] = v;
+            }
+        return;
+    }
     if (lane == 0) {
         g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
         if (wq.n > wq.cap) {
             // (the filtered passes rank cells by cosine, which is not the L2 order when norms differ: an L2 pair
             // whose fp16 strict list overflows is scored cell by cell)
-            const int flag = GENERAL ? 2 : (I8 ? 3 : (g.metric == SFM_METRIC_L2 ? 2 : 1));
+            const int flag = TWOSIDED ? 2 : (I8 ? 3 : (g.metric == SFM_METRIC_L2 ? 2 : 1));
             g.pairOvf[pr.chunkLocal] = flag;
             atomicAdd(&g.flagCount[flag], 1); // "some pair carries this flag", for the passes that walk the list
         }
@@ -872,12 +985,12 @@ __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const Ma
 // The later passes of the cosine metric redo flagged pairs only, usually none: a grid that just fills the
 // device walks the work list instead of launching a block per item to find that out.  Items b and b + 8
 // stay on one XCD as long as the grid is a multiple of 8.
-template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
+template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL, int MODE = 0>
 __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_walk_kernel(const MatchArgs g)
 {
     if (g.onlyFlagged && g.flagCount[g.onlyFlagged] == 0) return; // nothing to redo
     for (int item = blockIdx.x; item < g.nWork; item += gridDim.x) {
-        sim_block<FORM, DOT, GENERAL, ABL>(g, item);
+        sim_block<FORM, DOT, GENERAL, ABL, MODE>(g, item);
         __syncthreads(); // LDS of the item is free before the next one stages into it
     }
 }
@@ -906,6 +1019,8 @@ void sfm_launch_sim_signs(const MatchArgs &g, int blocks, hipStream_t st)
 }
 
 static void (*const kSimGeneral)(const MatchArgs) = match_sim_walk_kernel<2, false, false, true, 0>;
+static void (*const kSimRowMax)(const MatchArgs) = match_sim_walk_kernel<3, false, false, false, 0, 1>;
+static void (*const kSimBar)(const MatchArgs) = match_sim_walk_kernel<3, false, false, false, 0, 2>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
@@ -1283,14 +1398,14 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
     SET_HIP(s->desc8.reserve((size_t)r16 * 128));
     const size_t nImg = (size_t)(n_images ? n_images : 1);
-    SET_HIP(s->imageStats.reserve(nImg * 5 * sizeof(int))); // [n][2] int8 statistics, [n][2] norm range, [n] flags
+    SET_HIP(s->imageStats.reserve(nImg * 9 * sizeof(int))); // [n][2] int8 statistics, [n][2] norm range, [n] flags, [n][4] extent of the points
     SET_HIP(s->norms2.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(s->norms.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(s->imageRecs.reserve(nImg * sizeof(ImageRec)));
     // the padding rows of both tables must read as zero, and the per-image words start at zero
     SET_HIP(clear_ranges(ctx->stream, {{s->desc8.p, (size_t)r16 * 128},
                                        {s->desc16.p, (size_t)r16 * KDIM * sizeof(_Float16)},
-                                       {s->imageStats.p, nImg * 5 * sizeof(int)}}));
+                                       {s->imageStats.p, nImg * 9 * sizeof(int)}}));
     int *const imageFlags = s->imageStats.as<int>() + 4 * nImg;
     s->flags.assign(n_images, 0);
     if (n_images > 0 && maxN > 0) {
@@ -1299,7 +1414,8 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         dim3 g1((maxN + 63) / 64, n_images);
         hipLaunchKernelGGL(((dim & 3) == 0 ? ingest_rows_kernel<true> : ingest_rows_kernel<false>), g1, dim3(64), 0, ctx->stream,
                            s->desc32.as<float>(), s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->norms2.as<float>(),
-                           imageFlags, s->imageStats.as<int>(), s->imageStats.as<int>() + 2 * nImg, s->desc16.as<_Float16>());
+                           imageFlags, s->imageStats.as<int>(), s->imageStats.as<int>() + 2 * nImg, s->desc16.as<_Float16>(),
+                           s->pts.as<double2>(), s->imageStats.as<unsigned>() + 5 * nImg);
         // int8 table: per-image scale from the largest unit-normalised element (statistics stay on the device)
         dim3 g3(((int64_t)maxN * 8 + 255) / 256, n_images);
         hipLaunchKernelGGL(ingest_i8_kernel, g3, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
@@ -1360,7 +1476,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     if (r->statsEv) (void)hipEventDestroy(r->statsEv);
     r->hostStats.release();
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
-                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe};
+                      &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe, &r->rowMax};
     for (DevBuf *b : bufs) b->release();
     r->hostRecs.release();
     r->hostWork.release();
@@ -1546,7 +1662,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             r.ib = ib;
             r.thr_m = 0.0f; // pair_bounds_kernel fills the two bounds in on the device
             r.thr_i = 0;
-            r.pad_ = 0;
+            r.gateOff = 0;
         }
         for (int o = 0; o < 2; o++) {
             int2 *wl = work + chunkWorkBase[o][ci];
@@ -1605,6 +1721,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
     const size_t killSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(int)), 256);
     if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killSet * sets));
+    // two-phase filtered passes (cosine): one float per row of a chunk
+    const bool twoPhase = ctx->match_two_phase && metric == SFM_METRIC_COSINE && candCapMax > 0;
+    const size_t rowMaxSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(float)), 256);
+    if (twoPhase) SFM_HIP(ctx, res->rowMax.reserve(rowMaxSet * sets));
     // The single-pair entry point fetches everything with one copy: its count, the per-row and per-column bests
     // and the list lie side by side, [count: 16 B][m1: nA][m2: nB][(i, j): min(nA, nB)].
     unsigned char *packed = nullptr;
@@ -1680,7 +1800,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         if (wn > 0)
             SFM_HIP(ctx, hipMemcpyAsync(res->work.as<int2>() + w0, work + w0, (size_t)wn * sizeof(int2), hipMemcpyHostToDevice, up));
         const int nImg = set->n_images ? set->n_images : 1;
-        const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, nImg, set->dim, metric, threshold, ratio};
+        const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, set->imageStats.as<unsigned>() + 5 * (size_t)nImg,
+                             nImg, set->dim, metric, threshold, ratio, maxDistSq};
         hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, up, res->pairRecs.as<PairRec>() + c0, np, b);
         if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[7 + (int)(ci % (size_t)sets)], up));
         return SFM_OK;
@@ -1711,6 +1832,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         g.best = reinterpret_cast<u64 *>(bestBuf);
         g.ovfList = reinterpret_cast<int *>(res->ovfList.as<char>() + par * ovfListSet);
         g.kill = reinterpret_cast<int *>(killBuf);
+        g.rowMax = twoPhase ? reinterpret_cast<float *>(res->rowMax.as<char>() + par * rowMaxSet) : nullptr;
+        g.gateMode = 0;
         g.pairs = res->pairRecs.as<PairRec>() + c0;
         const int2 *workList[2] = {res->work.as<int2>() + chunkWorkBase[0][ci], res->work.as<int2>() + chunkWorkBase[1][ci]};
         g.work = workList[0];
@@ -1758,6 +1881,20 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
             // orientations.  Dot: every pair takes this path.
             g.onlyFlagged = cosine ? 1 : 0;
+            if (twoPhase) {
+                // Pairs whose pixel gate excludes nothing: every row's largest approximation, then a strict sweep
+                // against that bar, each with both images in the register-resident role.  The other flagged pairs
+                // take the filtered pass below.
+                g.gateMode = 1;
+                for (int phase = 0; phase < 2; phase++)
+                    for (int o = 0; o < 2; o++) {
+                        g.orient = o;
+                        g.work = workList[o];
+                        g.nWork = chunkWorkCount[o][ci];
+                        hipLaunchKernelGGL(phase == 0 ? kSimRowMax : kSimBar, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
+                    }
+                g.gateMode = 2;
+            }
             for (int o = 0; o < 2; o++) {
                 g.orient = o;
                 g.work = workList[o];
@@ -1767,6 +1904,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                                    dim3(SIM_WAVES * 64), 0, st, g);
                 if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
             }
+            g.gateMode = 0;
             if (probe) SFM_HIP(ctx, observe(st, np));
             if (overlap && !forked) {
                 SFM_HIP(ctx, hipEventRecord(ctx->ev[par], st));
@@ -2020,7 +2158,7 @@ extern "C" int64_t sfm_match_result_device_bytes(const sfm_match_result *r)
 {
     if (!r) return 0;
     const DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
-                            &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe};
+                            &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe, &r->rowMax};
     int64_t total = 0;
     for (const DevBuf *b : bufs) total += (int64_t)b->cap;
     return total;

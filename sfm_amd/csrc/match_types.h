@@ -13,7 +13,7 @@ struct PairRec {
     int32_t thr_i;          // the same bound on the int8 dot product (instances that use the int8 table)
     int32_t chunkLocal;     // index inside the chunk
     int32_t ia, ib;         // the two images in their set (float matcher: the bounds are made from their statistics on the device)
-    int32_t pad_;
+    int32_t gateOff;        // 1: the pixel gate cannot exclude any cell of this pair (made on the device with the bounds)
 };
 
 struct ImageRec {
@@ -41,7 +41,9 @@ struct MatchArgs {
     int *flagCount;       // [4]: how often a flag value was set in this chunk (only zero / non-zero matters)
     int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
     int nWork;            // entries of the work list (passes that walk it)
-    int orient;           // general pass: 0 = image A's rows stay in registers, 1 = image B's
+    int orient;           // filtered passes: 0 = image A's rows stay in registers, 1 = image B's
+    int gateMode;         // 0 = every pair; 1 = only pairs whose pixel gate excludes nothing; 2 = only the others
+    float *rowMax;        // [rows of the chunk, as best]: largest approximate cosine of each row (two-phase filtered passes)
     int maxQueues;        // slices per pair (row blocks * waves * column parts), upper bound over the batch
     int colSplit;         // strict passes: column parts per row block (0 or 1 = a block walks all columns); work item y = row block | part << 24
     u64 *best;            // row keys and column keys of the chunk
@@ -95,6 +97,7 @@ struct sfm_match_result {
     DevBuf pairRecs, work, cand, candCount, pairOvf, best, ovfList, counts, stats, m1, kill; // m1: packed outputs of a single-pair call
     PinBuf hostRecs, hostWork, hostOut; // hostOut: staging of the single-pair entry point's outputs
     int64_t total = -1;
+    DevBuf rowMax;           // two-phase filtered passes: a float per row of a chunk (per buffer set)
     DevBuf candProbe;        // lists of the first chunk of a call that observes how far they fill
     int candObserved = 0;    // candidate slots per pair sized from such a first chunk (0 = none yet)
     MatchKey observedFor = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};

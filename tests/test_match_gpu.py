@@ -479,3 +479,32 @@ def test_tables_in_page_locked_memory(ctx, oracle):
         got, g1, g2 = ctx.match_pair(*tabs, threshold=0.95, max_dist_sq=1e8, return_best=True)
         assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2)
     del tabs
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.0])
+def test_two_phase_sweeps_and_the_gate(ctx, oracle, thr):
+    """Pairs whose candidate lists overflow are redone with row maxima and a strict sweep against them when
+    their pixel gate excludes nothing, and with the filtered sweep otherwise.  Gates far above, just above and
+    just below the extent of the points, a point that is not finite, and the option that turns the two-phase
+    form off: always the restatement's lists."""
+    dA, pA, dB, pB = two_images(900, 1100, shared=0.5)
+    dA, dB = np.maximum(dA, 20), np.maximum(dB, 20)  # unrelated cosines ~0.8: every cell clears the threshold
+    allp = np.concatenate([pA, pB])
+    ext2 = float(((allp.max(axis=0) - allp.min(axis=0)) ** 2).sum())
+    for gate in (1e8, ext2 * 1.01, ext2 * 0.999, ext2 * 0.25):
+        for two_phase in (1, 0):
+            ctx.set_option("match_two_phase", two_phase)
+            try:
+                check_pair(ctx, oracle, dA, pA, dB, pB, thr, np.float32(gate))
+            finally:
+                ctx.set_option("match_two_phase", 1)
+    pB2 = pB.copy()
+    pB2[17, 0] = np.inf
+    pB2[33, 1] = np.nan
+    check_pair(ctx, oracle, dA, pA, dB, pB2, thr, 1e8)
+    counts = np.array([len(dA), len(dB)], np.int32)
+    s = ctx.imageset(counts, np.concatenate([dA, dB]), np.concatenate([pA, pB]))
+    res = s.match(np.array([[0, 1], [1, 0]], np.int32), threshold=thr, max_dist_sq=1e8)
+    assert res.stats_ex()[2] == 2, "both pairs were meant to need the filtered passes"
+    res.close()
+    s.close()
