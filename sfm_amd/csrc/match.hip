@@ -617,7 +617,8 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
             bits |= (unsigned)(v > thr_m && v >= localLo[idx]) << idx;
         }
     }
-    if (__builtin_amdgcn_ballot_w64(bits != 0) == 0) return;
+    const u64 lanesWithHits = __builtin_amdgcn_ballot_w64(bits != 0);
+    if (lanesWithHits == 0) return;
 
     // rare path
     const int z = opaque_zero();
@@ -634,6 +635,23 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
         // Every cell above the bound is queued.  The chain maxima say which quarter of the accumulators holds a
         // hit (typically one: a true match); its eight are compared one by one, the lane masks tested on the
         // scalar side, and only an accumulator with a hit somewhere in the wave pays for the queue.
+        // That is the cheap way while hits are sparse (true matches).  Where they are dense (a flooded pair
+        // being redone: several lanes with hits in the same step) each lane collects its 32 cells in a mask and
+        // the wave walks the masks together.
+        const bool sw = SWAP && g.orient != 0;
+        if (!INTEGER && __builtin_popcountll(lanesWithHits) > 2) { // (a flooded int8 pass gives up at once: sparse form only)
+            bits = 0;
+#pragma unroll
+            for (int idx = 0; idx < NV; idx++) bits |= (unsigned)(acc.get(idx) > thr_m) << idx;
+            while (__builtin_amdgcn_ballot_w64(bits != 0) != 0) {
+                const bool has = bits != 0;
+                const int bit = has ? __builtin_ctz(bits) : 0;
+                bits &= bits - 1;
+                const int i = rowBase + AccT::row(bit, ln), jj = colBase + AccT::col(bit, ln);
+                queue_push(wq, has && i < pr.nA && jj < pr.nB, sw ? jj : i, sw ? i : jj, lane);
+            }
+            return;
+        }
         const int rowLane = rowBase + 4 * (ln >> 4), colLane = colBase + (ln & 15);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -645,7 +663,6 @@ __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &
                 const bool hit = acc.get(idx) > thr_m;
                 if (__builtin_amdgcn_ballot_w64(hit) == 0) continue;
                 const int i = rowLane + ((idx & 15) >> 2) * 16 + (idx & 3), jj = colLane + (idx >> 4) * 16;
-                const bool sw = SWAP && g.orient != 0;
                 queue_push(wq, hit && i < pr.nA && jj < pr.nB, sw ? jj : i, sw ? i : jj, lane);
             }
         }
