@@ -3,6 +3,8 @@
 // reference's option structs, writes the results.
 //   test_frontend <case.bin> <out.bin>
 //   test_frontend --lifetime        (makes the thread's context and exits without releasing anything)
+//   test_frontend --time <case.bin> (wall time of match() and RANSAC() per call, as a caller of the reference sees them:
+//                                    packing of the keypoints, upload, kernels, download and the result vector included)
 // case.bin: int32 nA, nB, dim; float thr, gate; float descA[nA*dim]; double ptsA[2nA]; descB; ptsB;
 //           int32 n, maxIter; double maxSqErr, successProb; double K[9]; double x[2n]; double y[2n]
 // out.bin:  int32 nMatches; int32 pairs[2*nMatches]; int32 nInliers; int32 inliers[nInliers];
@@ -10,9 +12,11 @@
 //           int32 nMatchesPlugin; int32 pairs[...];                            (similarityMetric plug-in, CPU path)
 //           int32 nInliersPlugin; int32 inliers[...]                           (loss plug-in, CPU path)
 // The sample table's seed comes from the environment (SFM_AMD_RANSAC_SEED), as adaptors/ransac_amd.cpp reads it.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <iostream>
 
 #include "match/match.hpp"
@@ -76,8 +80,9 @@ static int lifetime()
 int main(int argc, char **argv)
 {
     if (argc == 2 && !strcmp(argv[1], "--lifetime")) return lifetime();
+    const bool timing = argc == 3 && !strcmp(argv[1], "--time");
     if (argc != 3) return 2;
-    FILE *f = fopen(argv[1], "rb");
+    FILE *f = fopen(argv[timing ? 2 : 1], "rb");
     if (!f) return 2;
     int32_t nA, nB, dim;
     float thr, gate;
@@ -107,6 +112,29 @@ int main(int argc, char **argv)
     match::MATCHING_OPTIONS mo;
     mo.threshold = thr;
     mo.maxDistancePxSquared = gate;
+    if (timing) {
+        solve::RANSAC_OPTIONS ro;
+        ro.maxIter = maxIter;
+        ro.maxTimeMs = 20000;
+        ro.maxSquaredError = maxSqErr;
+        ro.successProb = successProb;
+        auto per_call_ms = [](auto &&fn) {
+            for (int i = 0; i < 10; i++) fn();
+            double best = 1e30;
+            for (int round = 0; round < 3; round++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < 20; i++) fn();
+                best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 20);
+            }
+            return best;
+        };
+        size_t nm = 0, ni = 0;
+        const double tm = per_call_ms([&] { nm = match::match(kA, kB, mo).size(); });
+        const double tr = per_call_ms([&] { ni = solve::RANSAC(x, y, K, ro, false).size(); });
+        printf("match(): %.3f ms per call (%d x %d keypoints, %zu matches); RANSAC(): %.3f ms per call (%d correspondences, maxIter %d, %zu inliers)\n",
+               tm, nA, nB, nm, tr, n, maxIter, ni);
+        return 0;
+    }
     auto m = match::match(kA, kB, mo);
 
     // error behaviour of the reference: unknown algorithm throws std::invalid_argument (match.cpp:18)

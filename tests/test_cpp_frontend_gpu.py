@@ -80,3 +80,27 @@ def test_cpp_match_and_ransac(tmp_path, oracle):
     epose, epts, _, _ = oracle.eight_point(tv["x"][inl], tv["y"][inl])
     assert np.abs(got["pose"] - epose).max() < 1e-8
     assert len(got["points"]) == len(inl) and np.abs(got["points"] - epts).max() <= 1e-6 * np.abs(epts).max()
+
+
+def test_cpp_call_times(tmp_path):
+    """What a caller of the reference sees per call through the adaptors at the default run's sizes (8192 keypoints
+    per frame, ~4000 correspondences, 8192 iterations): printed with pytest -s; here only that the run succeeds and
+    stays far below the CPU path's seconds."""
+    d, p, counts, _ = synth.frame_sequence(2, 8192, seed=4242)
+    tv = synth.two_view(4000, inlier_ratio=0.8, seed=63, noise_px=0.3)
+    case = str(tmp_path / "time.bin")
+    with open(case, "wb") as f:
+        f.write(struct.pack("<iiiff", int(counts[0]), int(counts[1]), d.shape[1], 0.95, 1e4))
+        for a in (d[:counts[0]].astype(np.float32), p[:counts[0]].astype(np.float64), d[counts[0]:].astype(np.float32),
+                  p[counts[0]:].astype(np.float64)):
+            f.write(a.tobytes())
+        f.write(struct.pack("<iidd", len(tv["x"]), 8192, 1.0, 0.999))
+        f.write(np.asfortranarray(tv["K"]).reshape(-1, order="F").astype(np.float64).tobytes())
+        f.write(tv["x"].astype(np.float64).tobytes())
+        f.write(tv["y"].astype(np.float64).tobytes())
+    r = subprocess.run([EXE, "--time", case], capture_output=True, text=True, timeout=100, env=dict(os.environ, SFM_AMD_RANSAC_SEED="7"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    print(r.stdout.strip())
+    import re
+    t = [float(v) for v in re.findall(r"([0-9.]+) ms per call", r.stdout)]
+    assert len(t) == 2 and max(t) < 50.0
