@@ -270,7 +270,8 @@ def main():
             "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1), args.bound),
             "traffic_unit": "HBM bytes per launch",
             "traffic_source": "static, not measured in this run: bytes per pair from the committed rocprofv3 PMC passes "
-                              "(profiles/r1_pmc_traffic*.json: separate FETCH_SIZE / WRITE_SIZE runs of this script) "
+                              "(profiles/r2_pmc_traffic_i8.json, r1_pmc_traffic.json for the fp16 bound: separate FETCH_SIZE / WRITE_SIZE "
+                              "runs of this script, scripts/pmc_traffic.sh) "
                               "times this run's pairs per launch",
             "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4), "launches": kernel_launches,
             "flops_per_pair": flops_per_pair,
@@ -314,7 +315,7 @@ def measured_traffic(pairs_per_launch, bound="int8"):
     """HBM bytes per launch of the similarity kernel from the committed PMC pass (FETCH_SIZE and
     WRITE_SIZE are collected by rocprofv3 in separate runs of this script, not inline), scaled to
     this run's pairs per launch; None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic_i8.json" if bound == "int8" else "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic_i8.json" if bound == "int8" else "r1_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
