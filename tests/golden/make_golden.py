@@ -88,6 +88,21 @@ def ratio_cases():
     return cases
 
 
+def l2_cases():
+    """Mutual nearest neighbours under the squared Euclidean distance, with and without the second-best test (an
+    extension: the reference's metrics are cosine and dot)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from test_match_l2_gpu import scaled_sift
+    cases = {}
+    for name, n, seed, spread, T, gate, ratio in [("sift_400_spread20", 400, 21, 0.2, 250.0 ** 2, 1e8, 0.0),
+                                                  ("sift_300_spread50_r080_gate", 300, 22, 0.5, 260.0 ** 2, 150.0 ** 2, 0.8)]:
+        A, pA, B, pB = scaled_sift(n, seed, spread)
+        pairs, m1, m2 = oracle.match_l2(A, pA, B, pB, T, max_dist_sq=gate, ratio=ratio)
+        cases[name] = dict(descA=A, ptsA=pA, descB=B, ptsB=pB, max_distance_squared=np.float32(T), max_dist_sq=np.float32(gate),
+                           ratio=np.float32(ratio), pairs=pairs, matches1=m1, matches2=m2)
+    return cases
+
+
 def hamming_cases():
     """Binary descriptors under the Hamming distance (an extension: the reference has none)."""
     sys.path.insert(0, os.path.dirname(OUT))
@@ -129,7 +144,7 @@ def refit_cases():
 
 def main():
     oracle.build()
-    groups = [("match_", matcher_cases), ("ransac_", ransac_cases), ("ratio_", ratio_cases), ("hamming_", hamming_cases),
+    groups = [("match_", matcher_cases), ("ransac_", ransac_cases), ("ratio_", ratio_cases), ("l2_", l2_cases), ("hamming_", hamming_cases),
               ("chain_", chain_cases), ("refit_", refit_cases)]
     for prefix, make in groups:
         for name, c in make().items():

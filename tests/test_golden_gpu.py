@@ -43,6 +43,20 @@ def test_ratio_golden(ctx, path):
     s.close()
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "l2_*.npz"))), ids=os.path.basename)
+def test_l2_golden(ctx, path):
+    from sfm_amd import capi
+    g = np.load(path)
+    nA, nB = len(g["ptsA"]), len(g["ptsB"])
+    s = ctx.imageset(np.array([nA, nB], np.int32), np.concatenate([g["descA"], g["descB"]]),
+                     np.concatenate([g["ptsA"], g["ptsB"]]))
+    res = s.match(np.array([[0, 1]], np.int32), threshold=float(g["max_distance_squared"]), max_dist_sq=float(g["max_dist_sq"]),
+                  metric=capi.METRIC_L2, ratio=float(g["ratio"]))
+    assert np.array_equal(res.pairs(), g["pairs"])
+    res.close()
+    s.close()
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "hamming_*.npz"))), ids=os.path.basename)
 def test_hamming_golden(ctx, path):
     from sfm_amd import capi

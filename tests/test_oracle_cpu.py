@@ -47,6 +47,15 @@ def test_ratio_golden(oracle, path):
     assert 20 < len(pairs) < len(g["descA"])
 
 
+@pytest.mark.parametrize("path", golden("l2_"), ids=os.path.basename)
+def test_l2_golden(oracle, path):
+    g = np.load(path)
+    pairs, m1, m2 = oracle.match_l2(g["descA"], g["ptsA"], g["descB"], g["ptsB"], float(g["max_distance_squared"]),
+                                    max_dist_sq=float(g["max_dist_sq"]), ratio=float(g["ratio"]))
+    assert np.array_equal(pairs, g["pairs"]) and np.array_equal(m1, g["matches1"]) and np.array_equal(m2, g["matches2"])
+    assert 10 < len(pairs) < len(g["descA"])
+
+
 @pytest.mark.parametrize("path", golden("hamming_"), ids=os.path.basename)
 def test_hamming_golden(oracle, path):
     g = np.load(path)
