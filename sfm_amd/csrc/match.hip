@@ -1932,7 +1932,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             g.orient = 0;
             g.work = workList[0];
             const bool fast128 = set->dim == 128 && maxQueues <= 1024;
-            const int candBlocks = std::max(4, std::min(32, 2 * ctx->n_cus / np)); // blocks per pair of the exact pass
+            // blocks per pair of the exact pass: every block first sums the pair's slice counts, so few of them when
+            // the launch has many pairs (measured on 2048-pair chunks: 4.9 ms per step outside the similarity kernel
+            // with one or two, 5.6 with four, 6.5 with eight)
+            const int candBlocks = std::max(2, std::min(32, 2 * ctx->n_cus / np));
             if (candCap > 0) {
                 if (fast128)
                     hipLaunchKernelGGL((g.desc8u ? match_cand128_kernel<true, false> : match_cand128_kernel<false, false>),
