@@ -108,6 +108,8 @@ def main():
     ctx.set_option("sim_variant", sim_variant)
     if "SFM_MATCH_OVERLAP" in os.environ:  # A/B switch of the matcher's two-stream chunk overlap
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
+    if "SFM_RANSAC_MFMA" in os.environ:  # A/B switch: the RANSAC pre-test on the matrix cores (1) or the vector ALU (0)
+        ctx.set_option("ransac_mfma", int(os.environ["SFM_RANSAC_MFMA"]))
     if "SFM_MATCH_COL_SPLIT" in os.environ:  # A/B switch: column parts per row block of small matcher launches
         ctx.set_option("match_col_split", int(os.environ["SFM_MATCH_COL_SPLIT"]))
     if args.first_slice > 0:

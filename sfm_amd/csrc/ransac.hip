@@ -54,6 +54,8 @@ struct RansacArgs {
     double K[9]; // column-major
     double Ki[4]; // pre-test constants (valid when filter != 0): 1/fx, 1/fy, 1/min(fx,fy), max(fx,fy)^2
     int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
+    int mfma;     // 1: unsplit launches run the pre-test on the matrix cores (ransac_score_mfma_kernel)
+    int mfKe;     // and scale the hypothesis side of num by 2^mfKe
     double maxSqErr;
     double successProb;
     int H;
@@ -281,6 +283,8 @@ __device__ __forceinline__ void make_record(const RansacArgs &g, int64_t at, dou
     r[8] = (g.K[1] * b.x + g.K[4] * b.y) + g.K[7];
 }
 
+__device__ __forceinline__ double mfma_margin(const RansacArgs &g, double x1n2, double x2n2, double amax);
+
 __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, int64_t total)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,7 +322,10 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     d[12] = (float)(r[3] * g.K[4] / c);
     const double x1n = sqrt(r[9]), x2n = sqrt(r[4]);
     const double D = (1e-6 * c * g.Ki[2]) * x1n + 2e-6 * (x2n * x1n); // Ki[2] = 1 / min(fx, fy)
-    d[16] = tame ? (float)fmax(70.0 * (D * D), 1e-30) : INFINITY;       // (kept clear of the denormals)
+    double G = tame ? fmax(70.0 * (D * D), 1e-30) : INFINITY; // (kept clear of the denormals)
+    if (g.mfma && tame) // the matrix-core test needs a wider margin; the packed test stays valid with it
+        G = fmax(G, mfma_margin(g, r[9], r[4], fmax(fmax(fabs(r[0]), fabs(r[1])), 1.0) * fmax(fmax(fabs(r[2]), fabs(r[3])), 1.0)));
+    d[16] = (float)(G * 1.000001);
     if (kk == n - 1) // the rest of the last group is never read as a result
         for (int f = (kk & 3) + 1; f < 4; f++)
 #pragma unroll
@@ -868,6 +875,334 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
         g_scoreTimes[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------
+// scoring with the pre-test on the matrix cores
+// ---------------------------------------------------------------------------------------
+// The pre-test of ransac_score_kernel compares two forms that are each bilinear in a hypothesis and a
+// correspondence:
+//   num = x2h^T E x1h                      = sum over nine terms of  (x2h_i x1h_j) . E_ij
+//   q   = c^2 ((m0/fx)^2 + (m1/fy)^2)      = sum over six terms of   (monomial of x1h) . (entry of c^2 S),
+//         m = E x1h, S = E0^T E0 / fx^2 + E1^T E1 / fy^2 (E0, E1 the first two rows of E),
+// and skips the cell when num^2 >= q + G (G the margin of the correspondence).  Here both run as
+// v_mfma_f32_16x16x32_f16 on tiles of 16 hypotheses x 16 correspondences.  fp16 keeps 11 bits, so every operand
+// v is carried as hi + lo (hi = fp16(v), lo = fp16(v - hi): 22 bits) and a product as hi.hi + hi.lo + lo.hi --
+// three of the 32 K-slots per term: 27 for num; 18 for q plus two for G, which rides in q's sum (correspondence
+// side G hi/lo, hypothesis side a constant), so that one fused multiply-add per cell, d = num^2 - q', and the
+// sign of the smallest d of a lane's four cells decide.  Operands are scaled by powers of two into fp16's range
+// (MF_SA, 2^mfKe on the two sides of num; MF_SB and 2^(P-4) for q, P = 2 (10 + mfKe); 2^(P-6) and 64 for G).
+//
+// Margin.  With u = 2^-22 per operand (hi + lo), one more for the dropped lo.lo product, 27 additions in the
+// accumulator priced at 2^-22 each (the rounding of the matrix pipe's adder is not documented: this is four
+// times round-to-nearest), 4 . 2^-24 for the fp32 inputs of the products, and sum |a_k e_k| <= |a| |e| =
+// sqrt(2) |x1h| |x2h| (E = [T]x R has singular values 1, 1, 0):  |num - num*| <= 1.1e-5 |x1h| |x2h|.  Should
+// the pipe flush fp16 denormals (operands below 2^-14 after scaling), each operand is off by up to 2^-14 in
+// scaled units: 2 . 2^-14 (sum |e_k| / MF_SA + sum |a_k| / 2^mfKe) <= 5.2e-7 + 3.7e-4 / 2^mfKe |x1h| |x2h|.
+// D is the sum of the three; as in ransac_score_kernel, num^2 >= 1.02 q* + 70 D^2 then implies that the exact
+// distance is at least the skip distance, and the same accounting for q (21 additions, |monomials| <= |x1h|^2,
+// |entries| <= sqrt(2) c^2 (1/fx^2 + 1/fy^2)) adds 1.1 eps_q to the margin.  ransac_prep_kernel stores that G
+// when this kernel may run (it exceeds the packed test's margin, which stays valid with it).
+//
+// A wave holds the operands of 16 T hypotheses in registers and walks the pair's correspondences 16 at a
+// time (operands made from the fp32 records while a chunk is staged).  Survivors -- (row, correspondence)
+// cells, < 0.1 % -- go to one queue per wave and are evaluated exactly 64 at a time, whichever rows they
+// belong to; the queue is first-in first-out and a row's cells enter it in correspondence order, so adding
+// the inliers' errors to their rows in queue order reproduces the sequential sum (RANSAC.cpp:207-221).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#define MF_CH 128 // correspondences staged per step (two threads make the operands of one)
+#define MF_SA 1024.0f
+#define MF_SB 16.0f
+
+__device__ __forceinline__ void split_half(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// The margin of a correspondence for the matrix-core test (see above); inf when its operands would leave
+// fp16's range.  x1n2 = x1h.x1h, x2n2 = x2h.x2h, amax = max |x2h_i x1h_j|.
+__device__ __forceinline__ double mfma_margin(const RansacArgs &g, double x1n2, double x2n2, double amax)
+{
+    if (!(amax <= 32.0)) return INFINITY;
+    const double c = SKIP_FACTOR * sqrt(g.maxSqErr);
+    const double se = ldexp(1.0, g.mfKe), sQ = ldexp(1.0, 2 * (10 + g.mfKe) - 4);
+    const double D = (1.1e-5 + 3.7e-4 / se) * sqrt(x1n2 * x2n2) + 5.2e-7;
+    const double cfp = 1.4143 * (c * c) * (g.Ki[0] * g.Ki[0] + g.Ki[1] * g.Ki[1]);
+    const double epsq = (1.0e-5 * x1n2 + 1.9e-5) * cfp + 3.0e-4 * x1n2 / sQ;
+    return (70.0 * (D * D) + 1.1 * epsq) * 1.00001;
+}
+
+// Hypothesis side of both forms, 64 halves: [0, 32) for num, [32, 64) for q.  A row that is not in play
+// (valid = false) gets zeros: d = 0 for every correspondence, never a survivor.  A pose that is not a unit
+// translation and a rotation (entries of E beyond 1, or not finite) cannot be bounded: its row gets +inf on the
+// constant monomial, so that every cell of it survives.
+__device__ __forceinline__ void mfma_hyp_operands(const RansacArgs &g, const Pose &P, bool valid, _Float16 *out)
+{
+    double E[3][3];
+    essential_from_pose(P, E);
+    bool sane = true;
+#pragma unroll
+    for (int i = 0; i < 9; i++) sane = sane && (fabs(E[i / 3][i % 3]) <= 1.001);
+    const float se = ldexpf(1.0f, g.mfKe);
+    const double c = SKIP_FACTOR * sqrt(g.maxSqErr);
+    const double sQ = ldexp(c * c, 2 * (10 + g.mfKe) - 4);
+    const double ix2 = g.Ki[0] * g.Ki[0], iy2 = g.Ki[1] * g.Ki[1];
+    const int ja[6] = {0, 1, 2, 0, 0, 1}, jb[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+    for (int k = 0; k < 64; k++) out[k] = (_Float16)0.0f;
+    if (!valid) return;
+    if (!sane) {
+        out[32 + 6] = (_Float16)INFINITY;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        _Float16 hi, lo;
+        split_half((float)E[k / 3][k % 3] * se, hi, lo);
+        out[3 * k] = hi;
+        out[3 * k + 1] = lo;
+        out[3 * k + 2] = hi;
+    }
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+        const double S = (E[0][ja[m]] * E[0][jb[m]]) * ix2 + (E[1][ja[m]] * E[1][jb[m]]) * iy2;
+        _Float16 hi, lo;
+        split_half((float)((m < 3 ? S : 2.0 * S) * sQ), hi, lo);
+        out[32 + 3 * m] = hi;
+        out[32 + 3 * m + 1] = lo;
+        out[32 + 3 * m + 2] = hi;
+    }
+    out[32 + 18] = (_Float16)64.0f;
+    out[32 + 19] = (_Float16)64.0f;
+}
+
+// Correspondence side, from the fp32 record (x1, y1, fx x2 / c, fy y2 / c, G): 32 halves for num (side 0) or
+// 32 for q (side 1).  G = inf (not an ordinary pixel, or out of fp16's range): num's operands are zero and
+// q' = inf -- the cell survives whatever the hypothesis.
+__device__ __forceinline__ void mfma_corr_operands(const RansacArgs &g, int side, float x1, float y1, float u2, float v2,
+                                                   float G, _Float16 *out)
+{
+    const bool tame = G < INFINITY;
+#pragma unroll
+    for (int k = 0; k < 32; k++) out[k] = (_Float16)0.0f;
+    if (side == 0) {
+        const float c = (float)(SKIP_FACTOR * sqrt(g.maxSqErr));
+        const float x2h[3] = {u2 * (c * (float)g.Ki[0] * MF_SA), v2 * (c * (float)g.Ki[1] * MF_SA), MF_SA};
+        const float x1h[3] = {x1, y1, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            _Float16 hi, lo;
+            split_half(tame ? x2h[k / 3] * x1h[k % 3] : 0.0f, hi, lo);
+            out[3 * k] = hi;
+            out[3 * k + 1] = hi;
+            out[3 * k + 2] = lo;
+        }
+    } else {
+        const float mono[6] = {x1 * x1, y1 * y1, 1.0f, x1 * y1, x1, y1};
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            _Float16 hi, lo;
+            split_half(tame ? mono[m] * MF_SB : 0.0f, hi, lo);
+            out[3 * m] = hi;
+            out[3 * m + 1] = hi;
+            out[3 * m + 2] = lo;
+        }
+        _Float16 gh, gl;
+        split_half(tame ? G * ldexpf(1.0f, 2 * (10 + g.mfKe) - 6) : 0.0f, gh, gl);
+        out[18] = tame ? gh : (_Float16)INFINITY;
+        out[19] = tame ? gl : (_Float16)0.0f;
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ransac_score_mfma_kernel(const RansacArgs g)
+{
+    constexpr int ROWS_W = 16 * T, ROWS_B = 4 * ROWS_W;
+    static_assert(T % 4 == 0 && T <= 8, "a lane owns T / 4 rows of its wave");
+    // One drain site per step: the queue must take what a step can add (every cell of the wave's T tiles) on
+    // top of what a drain leaves (< 64).
+    constexpr int QCAP = 64 + T * 256;
+    constexpr int OPB_HALVES = 2 * MF_CH * 32; // num side, then q side
+    constexpr int SLICE_HALVES = 4 * 64 * 64;  // the hypothesis operands on their way into fragments
+    constexpr int SMEM_BYTES = (OPB_HALVES * 2 + 4 * QCAP * 4) > SLICE_HALVES * 2 ? (OPB_HALVES * 2 + 4 * QCAP * 4) : SLICE_HALVES * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+    _Float16 *opB = reinterpret_cast<_Float16 *>(smem);
+    unsigned int *pool = reinterpret_cast<unsigned int *>(smem + OPB_HALVES * 2) + (threadIdx.x >> 6) * QCAP;
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    if (!g.active[p]) return;
+    const int rowW0 = g.hBegin + (int)blockIdx.x * ROWS_B + wave * ROWS_W; // the wave's first row
+    const int nRowsW = max(0, min(ROWS_W, g.hEnd - rowW0));
+    const double *poseP = g.pose12 + (size_t)p * g.H * 12;
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = g.K[i];
+    const double thr = g.maxSqErr;
+
+    // hypothesis operands: every lane makes those of one row, the wave's slice of LDS turns them into fragments
+    half8 An[T], Aq[T];
+    {
+        _Float16 *slice = opB + wave * (64 * 64);
+#pragma unroll
+        for (int round = 0; round < T / 4; round++) {
+            const int hl = round * 64 + lane;
+            const bool valid = hl < nRowsW;
+            Pose P;
+            load_pose(poseP + (size_t)(valid ? rowW0 + hl : g.hBegin) * 12, P);
+            _Float16 ops[64];
+            mfma_hyp_operands(g, P, valid, ops);
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                half8 w;
+#pragma unroll
+                for (int i = 0; i < 8; i++) w[i] = ops[8 * v + i];
+                *reinterpret_cast<half8 *>(slice + lane * 64 + 8 * v) = w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) {
+                An[4 * round + tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + quad * 8);
+                Aq[4 * round + tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + 32 + quad * 8);
+            }
+        }
+        __syncthreads();
+    }
+
+    int count[T / 4];
+    double tot[T / 4];
+#pragma unroll
+    for (int i = 0; i < T / 4; i++) {
+        count[i] = 0;
+        tot[i] = 0.0;
+    }
+    int qHead = 0, qCount = 0; // wave-uniform
+    auto drain = [&](int take) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int hl = 0;
+        double e = 0.0;
+        bool inl = false;
+        if (lane < take) {
+            int at = qHead + lane;
+            if (at >= QCAP) at -= QCAP;
+            const unsigned ent = pool[at];
+            const int k = (int)(ent & 0xFFFFFFu);
+            hl = (int)(ent >> 24);
+            Pose Q;
+            load_pose(poseP + (size_t)(rowW0 + hl) * 12, Q);
+            double r[9];
+            make_record(g, base + k, r);
+            e = reprojection_loss(K, Q, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            inl = e < thr; // RANSAC.cpp:216
+        }
+        qHead += take;
+        if (qHead >= QCAP) qHead -= QCAP;
+        qCount -= take;
+        // inliers in queue order, each added to its row (lane hl % 64 keeps the sums of rows hl, hl + 64)
+        unsigned long long m = __builtin_amdgcn_ballot_w64(inl);
+        const int elo = __double2loint(e), ehi = __double2hiint(e);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int h1 = __builtin_amdgcn_readlane(hl, l);
+            const double e1 = __hiloint2double(__builtin_amdgcn_readlane(ehi, l), __builtin_amdgcn_readlane(elo, l));
+            if (lane == (h1 & 63)) {
+#pragma unroll
+                for (int i = 0; i < T / 4; i++)
+                    if ((h1 >> 6) == i) {
+                        count[i]++;
+                        tot[i] += e1;
+                    }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    const float *rec32g = g.rec32 + rec32_start(base, p);
+    unsigned hwId;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
+    unsigned turn = hwId & 3; // the waves of a SIMD take turns at the top priority (see ransac_score_kernel)
+    const floatx4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k0 = 0; k0 < n; k0 += MF_CH) {
+        const int m = min(MF_CH, n - k0);
+        switch (turn++ & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+        { // stage: two threads per correspondence, one side each (zeros past the pair's last: d = 0)
+            const int kk = tid >> 1, side = tid & 1;
+            _Float16 ob[32];
+            if (kk < m) {
+                const float *grp = rec32g + (size_t)((k0 + kk) >> 2) * 20 + ((k0 + kk) & 3);
+                mfma_corr_operands(g, side, grp[0], grp[4], grp[8], grp[12], grp[16], ob);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; i++) ob[i] = (_Float16)0.0f;
+            }
+            _Float16 *dst = opB + side * (MF_CH * 32) + kk * 32;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                half8 a;
+#pragma unroll
+                for (int i = 0; i < 8; i++) a[i] = ob[8 * v + i];
+                *reinterpret_cast<half8 *>(dst + 8 * v) = a;
+            }
+        }
+        __syncthreads();
+        if (nRowsW > 0) {
+            const int steps = (m + 15) >> 4;
+            for (int s = 0; s < steps; s++) {
+                const half8 bn = *reinterpret_cast<const half8 *>(opB + (s * 16 + col) * 32 + quad * 8);
+                const half8 bq = *reinterpret_cast<const half8 *>(opB + MF_CH * 32 + (s * 16 + col) * 32 + quad * 8);
+                const int k = k0 + s * 16 + col;
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const floatx4 nu = __builtin_amdgcn_mfma_f32_16x16x32_f16(An[t], bn, zero, 0, 0, 0);
+                    const floatx4 qq = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[t], bq, zero, 0, 0, 0);
+                    floatx4 d;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) d[r] = __builtin_fmaf(nu[r], nu[r], -qq[r]);
+                    // (operands are built so that d is never NaN for a row in play; fminf drops a NaN)
+                    const float least = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                    if (__builtin_amdgcn_ballot_w64(!(least >= 0.0f)) == 0) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int hl = t * 16 + quad * 4 + r;
+                        const bool hit = !(d[r] >= 0.0f) && hl < nRowsW && k < n;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                        if (mask == 0) continue;
+                        if (hit) {
+                            int at = qHead + qCount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                            if (at >= QCAP) at -= QCAP;
+                            pool[at] = (unsigned)k | ((unsigned)hl << 24);
+                        }
+                        qCount += __builtin_popcountll(mask);
+                    }
+                }
+                while (qCount >= 64) drain(64);
+            }
+        }
+        __syncthreads();
+    }
+    if (qCount > 0) drain(qCount);
+#pragma unroll
+    for (int i = 0; i < T / 4; i++) {
+        const int hl = i * 64 + lane;
+        if (hl < nRowsW) {
+            g.counts[(size_t)p * g.H + rowW0 + hl] = count[i];
+            g.toterr[(size_t)p * g.H + rowW0 + hl] = tot[i];
+        }
+    }
 }
 
 // Second half of a split scoring launch: every row adds up its inliers' errors in correspondence
@@ -1658,6 +1993,20 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         g.Ki[3] = ok ? std::max(fx, fy) * std::max(fx, fy) : 0.0;          // bound of |m|^2 from the scaled line
     }
     g.maxSqErr = maxSqErr;
+    g.mfma = 0;
+    if (g.filter && ctx->ransac_mfma && maxSqErr > 0.0 && std::isfinite(maxSqErr)) {
+        // scale of the hypothesis side: the largest entry of the q form, 2 c^2 (1/fx^2 + 1/fy^2) 2^(P-4) with
+        // P = 2 (10 + mfKe), must stay inside fp16 (2^15 here)
+        const double c2 = SKIP_FACTOR * SKIP_FACTOR * maxSqErr;
+        const double cf2 = c2 * (g.Ki[0] * g.Ki[0] + g.Ki[1] * g.Ki[1]);
+        const int ke = (int)std::floor((18.0 - std::log2(cf2)) / 2.0 - 10.0);
+        bool fits = ke >= -4; // (a threshold of hundreds of focal lengths: the packed test serves)
+        for (int p = 0; p < n_pairs && fits; p++) fits = corr_offsets[p + 1] - corr_offsets[p] < (1 << 24); // queue entries
+        if (fits) {
+            g.mfma = 1;
+            g.mfKe = std::min(ke, 10);
+        }
+    }
     g.successProb = successProb;
     g.H = n_hyp;
     g.adaptive = adaptive;
@@ -1723,7 +2072,10 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             else
                 score = Z > 1 ? ransac_score_kernel<SFM_LOSS_REPROJECTION, true, false>
                               : ransac_score_kernel<SFM_LOSS_REPROJECTION, false, false>;
-            hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
+            if (pretest && Z == 1 && g.mfma && loss == SFM_LOSS_REPROJECTION)
+                hipLaunchKernelGGL(ransac_score_mfma_kernel<4>, dim3((rows + 255) / 256, n_pairs), dim3(256), 0, st, g);
+            else
+                hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
             if (Z > 1) {
                 if ((int64_t)n_pairs * ((rows + 63) / 64) >= ctx->n_cus)
                     hipLaunchKernelGGL(ransac_sum_kernel<64>, dim3((rows + 63) / 64, n_pairs), dim3(SUM_THREADS), 0, st, g, eb);

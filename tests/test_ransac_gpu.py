@@ -434,3 +434,42 @@ def test_eight_point_from_subset(ctx, oracle):
     with pytest.raises(capi.SfmError) as e:
         ctx.eight_point_from_subset(tv["x"][:7], tv["y"][:7], tv["x"], tv["y"])
     assert e.value.code == capi.ERR_INVALID_ARG and "at least 8" in str(e.value)
+
+
+@pytest.mark.parametrize("ratio,thr,n,H", [(0.15, 1.0, 5000, 1024), (0.5, 1.0, 3000, 512), (0.9, 4.0, 2100, 300),
+                                           (0.3, 1e-2, 1999, 257), (0.6, 1e4, 1500, 256), (1.0, 1.0, 777, 130)])
+def test_matrix_core_pretest_is_bit_identical(ctx, oracle, ratio, thr, n, H):
+    """Unsplit scoring launches run the pre-test on the matrix cores: per-row counts, error sums and the inlier
+    list are those of the packed fp32 test, of no pre-test at all, and of the CPU restatement -- also with
+    observations at the epipoles, far outside the image and at the origin."""
+    tv = synth.two_view(n, inlier_ratio=ratio, seed=1000 + n, noise_px=0.7)
+    x, y = tv["x"].copy(), tv["y"].copy()
+    S = synth.sample_table(n, H, seed=77 + H)
+    R, T = tv["R"], tv["T"]
+    e1, e2 = -R.T @ T, T
+    for k in range(10):
+        x[100 + k] = e1[:2] / e1[2] + (k % 5) * 1e-7
+        y[120 + k] = e2[:2] / e2[2] + (k % 7) * 1e-9
+    x[50] = [1e9, -1e9]
+    y[51] = [1e7, 2e7]
+    x[52] = y[52] = [0.0, 0.0]
+    x[53] = [40.0, -3.0]  # ordinary pixels, but products beyond what the fp16 operands carry
+    y[53] = [-2.0, 30.0]
+    res = {}
+    ctx.set_option("ransac_split", 0)
+    try:
+        for name, flt, mf in (("mfma", 1, 1), ("packed", 1, 0), ("off", 0, 0)):
+            ctx.set_option("ransac_filter", flt)
+            ctx.set_option("ransac_mfma", mf)
+            res[name] = ctx.ransac_pair(x, y, tv["K"], S, max_sq_err=thr, adaptive=False)
+    finally:
+        ctx.set_option("ransac_split", 1)
+        ctx.set_option("ransac_filter", 1)
+        ctx.set_option("ransac_mfma", 1)
+    for other in ("packed", "off"):
+        assert np.array_equal(res["mfma"]["counts"], res[other]["counts"]), other
+        assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), res[other]["toterr"].view(np.uint64)), other
+        assert np.array_equal(res["mfma"]["inliers"], res[other]["inliers"]), other
+    exp = oracle.ransac(x, y, tv["K"], S, max_sq_err=thr, adaptive=False)
+    assert np.array_equal(res["mfma"]["counts"], exp["counts"]) and np.array_equal(res["mfma"]["inliers"], exp["inliers"])
+    assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), np.asarray(exp["toterr"]).view(np.uint64))
