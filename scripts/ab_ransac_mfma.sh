@@ -3,7 +3,7 @@
 # shapes where a model is found.  Output: gpurun_out/ab_ransac_mfma_<tag>_{1,0}.json
 tag=${1:-x}
 mkdir -p gpurun_out
-for v in 1 0; do
+for v in ${VARIANTS:-1 0}; do
   SFM_RANSAC_MFMA=$v timeout -k 10 400 python bench.py --images 40 --no-cpu-baseline --no-pipeline --no-extensions \
     > gpurun_out/ab_ransac_mfma_${tag}_$v.json 2> gpurun_out/ab_ransac_mfma_${tag}_$v.err || exit 1
   python - <<PY

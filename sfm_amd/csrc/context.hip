@@ -129,7 +129,7 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "ransac_filter")) {
         ctx->ransac_filter = value != 0;
     } else if (!strcmp(key, "ransac_mfma")) {
-        ctx->ransac_mfma = value != 0;
+        ctx->ransac_mfma = (int)value;
     } else if (!strcmp(key, "ransac_seed")) {
         ctx->ransac_seed = (uint64_t)value;
     } else if (!strcmp(key, "ransac_max_time_ms")) {

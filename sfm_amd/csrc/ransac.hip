@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
 // the inliers' errors to their rows in queue order reproduces the sequential sum (RANSAC.cpp:207-221).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-#define MF_CH 128 // correspondences staged per step (two threads make the operands of one)
+#define MF_CH 128 // correspondences staged per step (two threads make the operands of one: 256 threads, 2 sides)
 #define MF_SA 1024.0f
 #define MF_SB 16.0f
 
@@ -936,8 +936,9 @@ __device__ __forceinline__ double mfma_margin(const RansacArgs &g, double x1n2, 
 
 // Hypothesis side of both forms, 64 halves: [0, 32) for num, [32, 64) for q.  A row that is not in play
 // (valid = false) gets zeros: d = 0 for every correspondence, never a survivor.  A pose that is not a unit
-// translation and a rotation (entries of E beyond 1, or not finite) cannot be bounded: its row gets +inf on the
-// constant monomial, so that every cell of it survives.
+// translation and a rotation (entries of E beyond 1, or not finite) cannot be bounded: its row gets zeros for
+// num and fp16's largest value on the constant monomial, so that every cell of it survives (d < 0).  No operand
+// is ever inf or NaN, so no d is NaN and "d < 0" is the whole test.
 __device__ __forceinline__ void mfma_hyp_operands(const RansacArgs &g, const Pose &P, bool valid, _Float16 *out)
 {
     double E[3][3];
@@ -953,8 +954,10 @@ __device__ __forceinline__ void mfma_hyp_operands(const RansacArgs &g, const Pos
 #pragma unroll
     for (int k = 0; k < 64; k++) out[k] = (_Float16)0.0f;
     if (!valid) return;
+    out[32 + 18] = (_Float16)-64.0f; // (the q side is negated: the matrix cores deliver -q', and d = num^2 + (-q'))
+    out[32 + 19] = (_Float16)-64.0f;
     if (!sane) {
-        out[32 + 6] = (_Float16)INFINITY;
+        out[32 + 6] = (_Float16)-65504.0f;
         return;
     }
 #pragma unroll
@@ -969,25 +972,24 @@ __device__ __forceinline__ void mfma_hyp_operands(const RansacArgs &g, const Pos
     for (int m = 0; m < 6; m++) {
         const double S = (E[0][ja[m]] * E[0][jb[m]]) * ix2 + (E[1][ja[m]] * E[1][jb[m]]) * iy2;
         _Float16 hi, lo;
-        split_half((float)((m < 3 ? S : 2.0 * S) * sQ), hi, lo);
+        split_half((float)(-(m < 3 ? S : 2.0 * S) * sQ), hi, lo);
         out[32 + 3 * m] = hi;
         out[32 + 3 * m + 1] = lo;
         out[32 + 3 * m + 2] = hi;
     }
-    out[32 + 18] = (_Float16)64.0f;
-    out[32 + 19] = (_Float16)64.0f;
 }
 
 // Correspondence side, from the fp32 record (x1, y1, fx x2 / c, fy y2 / c, G): 32 halves for num (side 0) or
 // 32 for q (side 1).  G = inf (not an ordinary pixel, or out of fp16's range): num's operands are zero and
-// q' = inf -- the cell survives whatever the hypothesis.
+// q' is huge -- the cell survives whatever the hypothesis in play.
 __device__ __forceinline__ void mfma_corr_operands(const RansacArgs &g, int side, float x1, float y1, float u2, float v2,
                                                    float G, _Float16 *out)
 {
-    const bool tame = G < INFINITY;
+    const bool tameIn = G < INFINITY;
 #pragma unroll
     for (int k = 0; k < 32; k++) out[k] = (_Float16)0.0f;
     if (side == 0) {
+        const bool tame = tameIn && G * ldexpf(1.0f, 2 * (10 + g.mfKe) - 6) < 65000.0f;
         const float c = (float)(SKIP_FACTOR * sqrt(g.maxSqErr));
         const float x2h[3] = {u2 * (c * (float)g.Ki[0] * MF_SA), v2 * (c * (float)g.Ki[1] * MF_SA), MF_SA};
         const float x1h[3] = {x1, y1, 1.0f};
@@ -1001,6 +1003,10 @@ __device__ __forceinline__ void mfma_corr_operands(const RansacArgs &g, int side
         }
     } else {
         const float mono[6] = {x1 * x1, y1 * y1, 1.0f, x1 * y1, x1, y1};
+        _Float16 gh, gl;
+        const float Gs = G * ldexpf(1.0f, 2 * (10 + g.mfKe) - 6);
+        const bool tame = tameIn && Gs < 65000.0f;
+        split_half(tame ? Gs : 0.0f, gh, gl);
 #pragma unroll
         for (int m = 0; m < 6; m++) {
             _Float16 hi, lo;
@@ -1009,15 +1015,13 @@ __device__ __forceinline__ void mfma_corr_operands(const RansacArgs &g, int side
             out[3 * m + 1] = hi;
             out[3 * m + 2] = lo;
         }
-        _Float16 gh, gl;
-        split_half(tame ? G * ldexpf(1.0f, 2 * (10 + g.mfKe) - 6) : 0.0f, gh, gl);
-        out[18] = tame ? gh : (_Float16)INFINITY;
+        out[18] = tame ? gh : (_Float16)65504.0f; // (a margin beyond fp16's range saturates the same way)
         out[19] = tame ? gl : (_Float16)0.0f;
     }
 }
 
 template <int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ransac_score_mfma_kernel(const RansacArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 : 3))) void ransac_score_mfma_kernel(const RansacArgs g)
 {
     constexpr int ROWS_W = 16 * T, ROWS_B = 4 * ROWS_W;
     static_assert(T % 4 == 0 && T <= 8, "a lane owns T / 4 rows of its wave");
@@ -1131,6 +1135,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
     unsigned turn = hwId & 3; // the waves of a SIMD take turns at the top priority (see ransac_score_kernel)
     const floatx4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    float recNext[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch = [&](int kFirst) __attribute__((always_inline)) {
+        const int k = kFirst + (tid & (MF_CH - 1));
+        if (k < n) {
+            const float *grp = rec32g + (size_t)(k >> 2) * 20 + (k & 3);
+#pragma unroll
+            for (int f = 0; f < 5; f++) recNext[f] = grp[4 * f];
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < n; k0 += MF_CH) {
         const int m = min(MF_CH, n - k0);
         switch (turn++ & 3) {
@@ -1140,51 +1154,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         default: __builtin_amdgcn_s_setprio(3); break;
         }
         { // stage: two threads per correspondence, one side each (zeros past the pair's last: d = 0)
-            const int kk = tid >> 1, side = tid & 1;
+            const int kk = tid & (MF_CH - 1), side = tid >> 7; // (a wave makes one side: no divergence)
             _Float16 ob[32];
             if (kk < m) {
-                const float *grp = rec32g + (size_t)((k0 + kk) >> 2) * 20 + ((k0 + kk) & 3);
-                mfma_corr_operands(g, side, grp[0], grp[4], grp[8], grp[12], grp[16], ob);
+                mfma_corr_operands(g, side, recNext[0], recNext[1], recNext[2], recNext[3], recNext[4], ob);
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; i++) ob[i] = (_Float16)0.0f;
             }
-            _Float16 *dst = opB + side * (MF_CH * 32) + kk * 32;
+            // fragment order: [step of 16][K-octet][correspondence of the step][8 halves] -- the 64 lanes of a
+            // fragment read (and the 64 of a write) cover 1 KB without a gap
+            _Float16 *dst = opB + side * (MF_CH * 32) + (kk >> 4) * 512 + (kk & 15) * 8;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 half8 a;
 #pragma unroll
                 for (int i = 0; i < 8; i++) a[i] = ob[8 * v + i];
-                *reinterpret_cast<half8 *>(dst + 8 * v) = a;
+                *reinterpret_cast<half8 *>(dst + v * 128) = a;
             }
         }
+        fetch(k0 + MF_CH); // the next chunk's records travel while this one is tested
         __syncthreads();
         if (nRowsW > 0) {
             const int steps = (m + 15) >> 4;
             for (int s = 0; s < steps; s++) {
-                const half8 bn = *reinterpret_cast<const half8 *>(opB + (s * 16 + col) * 32 + quad * 8);
-                const half8 bq = *reinterpret_cast<const half8 *>(opB + MF_CH * 32 + (s * 16 + col) * 32 + quad * 8);
+                const half8 bn = *reinterpret_cast<const half8 *>(opB + s * 512 + lane * 8);
+                const half8 bq = *reinterpret_cast<const half8 *>(opB + MF_CH * 32 + s * 512 + lane * 8);
                 const int k = k0 + s * 16 + col;
+                floatx4 nu[T], qq[T];
 #pragma unroll
                 for (int t = 0; t < T; t++) {
-                    const floatx4 nu = __builtin_amdgcn_mfma_f32_16x16x32_f16(An[t], bn, zero, 0, 0, 0);
-                    const floatx4 qq = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[t], bq, zero, 0, 0, 0);
-                    floatx4 d;
+                    nu[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(An[t], bn, zero, 0, 0, 0);
+                    qq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[t], bq, zero, 0, 0, 0);
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; r++) d[r] = __builtin_fmaf(nu[r], nu[r], -qq[r]);
-                    // (operands are built so that d is never NaN for a row in play; fminf drops a NaN)
+                for (int t = 0; t < T; t++) {
+                    // d = num^2 - q' per cell; no operand is inf or NaN, so neither is d
+                    const f32x2 dA = __builtin_elementwise_fma(f32x2{nu[t][0], nu[t][1]}, f32x2{nu[t][0], nu[t][1]}, f32x2{qq[t][0], qq[t][1]});
+                    const f32x2 dB = __builtin_elementwise_fma(f32x2{nu[t][2], nu[t][3]}, f32x2{nu[t][2], nu[t][3]}, f32x2{qq[t][2], qq[t][3]});
+                    const float d[4] = {dA.x, dA.y, dB.x, dB.y};
                     const float least = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-                    if (__builtin_amdgcn_ballot_w64(!(least >= 0.0f)) == 0) continue;
+                    if (__builtin_amdgcn_fcmpf(least, 0.0f, 4) == 0) continue; // 4: ordered <
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int hl = t * 16 + quad * 4 + r;
-                        const bool hit = !(d[r] >= 0.0f) && hl < nRowsW && k < n;
+                        const bool hit = d[r] < 0.0f;
                         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
                         if (mask == 0) continue;
                         if (hit) {
                             int at = qHead + qCount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                             if (at >= QCAP) at -= QCAP;
-                            pool[at] = (unsigned)k | ((unsigned)hl << 24);
+                            pool[at] = (unsigned)k | ((unsigned)(t * 16 + quad * 4 + r) << 24);
                         }
                         qCount += __builtin_popcountll(mask);
                     }
@@ -2073,7 +2092,10 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                 score = Z > 1 ? ransac_score_kernel<SFM_LOSS_REPROJECTION, true, false>
                               : ransac_score_kernel<SFM_LOSS_REPROJECTION, false, false>;
             if (pretest && Z == 1 && g.mfma && loss == SFM_LOSS_REPROJECTION)
-                hipLaunchKernelGGL(ransac_score_mfma_kernel<4>, dim3((rows + 255) / 256, n_pairs), dim3(256), 0, st, g);
+                if (ctx->ransac_mfma == 2)
+                    hipLaunchKernelGGL(ransac_score_mfma_kernel<8>, dim3((rows + 511) / 512, n_pairs), dim3(256), 0, st, g);
+                else
+                    hipLaunchKernelGGL(ransac_score_mfma_kernel<4>, dim3((rows + 255) / 256, n_pairs), dim3(256), 0, st, g);
             else
                 hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
             if (Z > 1) {
