@@ -572,9 +572,25 @@ def ransac_inputs(torch, dev, pairs, distinct, n_corr, hyps, ratio, seed):
     return xd, yd, sd
 
 
-def ransac_valu_profile():
-    """Vector-ALU instructions the scoring kernel executes per wave and four correspondences on the stress
-    shape, from the committed counter pass (static; None if the file is absent)."""
+def ransac_valu_profile(mfma):
+    """Vector-ALU instructions the scoring kernel executes per wave and group of correspondences on the stress
+    shape, from the committed counter pass of the kernel that runs (static; None if the file is absent).
+    Returns (instructions, correspondences per group, extra fields, source)."""
+    if mfma:
+        path = os.path.join(ROOT, "profiles", "r2b_pmc_sq_ransac_mfma.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                t = json.load(f)
+            for k, v in t.items():
+                if isinstance(v, dict) and "ransac_score_mfma_kernel" in k:
+                    extra = {"kernel": "ransac_score_mfma_kernel",
+                             "vector_instructions_per_wave_per_16_correspondences": v["vector_instructions_per_wave_step"],
+                             "of_which_mfma": v["mfma_instructions_per_wave_step"],
+                             "matrix_pipe_busy_fraction_of_simd_cycles_under_counters": round(v["mfma_busy_fraction_of_simd_cycles"], 4),
+                             "valu_busy_fraction_of_simd_cycles_under_counters": round(v["valu_busy_fraction_of_simd_cycles"], 4),
+                             "clock_GHz_under_counters": round(v["clock_GHz_under_load"], 3)}
+                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/r2b_pmc_sq_ransac_mfma.json"
+        return None, None, None, None
     for name in ("r2_pmc_sq_ransac.json", "r1_final4_pmc_sq_ransac.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -582,8 +598,9 @@ def ransac_valu_profile():
                 t = json.load(f)
             for k, v in t.items():
                 if isinstance(v, dict) and "ransac_score_kernel<0, false, true>" in k:
-                    return v.get("valu_instructions_per_wave_per_four_correspondences"), "profiles/" + name
-    return None, None
+                    per4 = v.get("valu_instructions_per_wave_per_four_correspondences")
+                    return per4, 4, {"kernel": "ransac_score_kernel", "valu_instructions_per_wave_per_four_correspondences": per4}, "profiles/" + name
+    return None, None, None, None
 
 
 def bench_ransac(ctx, args, rank, world, dist, local_rank):
@@ -634,16 +651,19 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
     el, kms, launches, best = measure(P, args.ransac_distinct, 0.15, True, 1, steps, rank)
     hyps = P * H * steps * world
     pairs_s = P * steps * world / el
-    per4, src = ransac_valu_profile()
+    mfma_on = int(os.environ.get("SFM_RANSAC_MFMA", "1")) != 0  # the library's default; the stress shape meets its conditions
+    per_grp, grp, extra, src = ransac_valu_profile(mfma_on)
     valu = None
-    if per4 and kms > 0:
-        insts = (P * H / 64.0) * (n / 4.0) * per4 * steps  # wave-instructions of this rank's timed launches
+    if per_grp and kms > 0:
+        insts = (P * H / 64.0) * (n / float(grp)) * per_grp * steps  # wave-instructions of this rank's timed launches
         rate = insts / (kms * 1e-3) / 1e9
         valu = {"bound": "valu issue", "achieved": round(rate, 1), "peak": PEAK_VALU_GINST, "unit": "G wave-instructions/s",
-                "frac": round(rate / PEAK_VALU_GINST, 4), "valu_instructions_per_wave_per_four_correspondences": per4,
-                "source": f"static, not measured in this run: SQ_INSTS_VALU of the scoring kernel from {src} "
+                "frac": round(rate / PEAK_VALU_GINST, 4)}
+        valu.update(extra)
+        valu["source"] = (f"static, not measured in this run: SQ_INSTS_VALU of the scoring kernel from {src} "
                           "(rocprofv3 --pmc pass of this script on the stress shape) scaled to this run's waves; peak = 1024 SIMDs x "
-                          "2.4 GHz / 4 cycles per wave64 instruction"}
+                          "2.4 GHz / 4 cycles per wave64 instruction (matrix instructions are issued through the same port and "
+                          "are counted among the vector instructions)")
     out = {
         "metric": "RANSAC hyps scored/sec", "value": round(hyps / el, 1), "unit": "hyps/s",
         "what_it_measures": "15 % inliers, 4096 eight-point samples: no all-inlier sample exists, so every hypothesis is a "
