@@ -110,6 +110,8 @@ def main():
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
     if "SFM_RANSAC_MFMA" in os.environ:  # A/B switch: the RANSAC pre-test on the matrix cores (1) or the vector ALU (0)
         ctx.set_option("ransac_mfma", int(os.environ["SFM_RANSAC_MFMA"]))
+    if "SFM_RANSAC_MFMA_OPS_GIB" in os.environ:  # A/B switch: 0 = every block makes the matrix-core operands of its correspondences
+        ctx.set_option("ransac_mfma_ops_gib", int(os.environ["SFM_RANSAC_MFMA_OPS_GIB"]))
     if "SFM_MATCH_COL_SPLIT" in os.environ:  # A/B switch: column parts per row block of small matcher launches
         ctx.set_option("match_col_split", int(os.environ["SFM_MATCH_COL_SPLIT"]))
     if args.first_slice > 0:
@@ -577,7 +579,7 @@ def ransac_valu_profile(mfma):
     shape, from the committed counter pass of the kernel that runs (static; None if the file is absent).
     Returns (instructions, correspondences per group, extra fields, source)."""
     if mfma:
-        path = os.path.join(ROOT, "profiles", "r2b_pmc_sq_ransac_mfma.json")
+        path = os.path.join(ROOT, "profiles", "r2c_pmc_sq_ransac_mfma.json")
         if os.path.exists(path):
             with open(path) as f:
                 t = json.load(f)
@@ -589,7 +591,7 @@ def ransac_valu_profile(mfma):
                              "matrix_pipe_busy_fraction_of_simd_cycles_under_counters": round(v["mfma_busy_fraction_of_simd_cycles"], 4),
                              "valu_busy_fraction_of_simd_cycles_under_counters": round(v["valu_busy_fraction_of_simd_cycles"], 4),
                              "clock_GHz_under_counters": round(v["clock_GHz_under_load"], 3)}
-                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/r2b_pmc_sq_ransac_mfma.json"
+                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/r2c_pmc_sq_ransac_mfma.json"
         return None, None, None, None
     for name in ("r2_pmc_sq_ransac.json", "r1_final4_pmc_sq_ransac.json"):
         path = os.path.join(ROOT, "profiles", name)

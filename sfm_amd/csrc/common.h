@@ -28,6 +28,7 @@ struct sfm_ctx {
     int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
     int ransac_mfma = 1;             // 0: the pre-test of unsplit launches stays on the vector ALU (packed fp32)
+    int ransac_mfma_ops_gib = 64;    // largest table of prepared matrix-core operands (128 B per correspondence) a call may hold, GiB; 0: none
     int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
     int match_col_split = 0;         // column parts per row block in the matcher's strict passes; 0 = chosen per call from the launch size

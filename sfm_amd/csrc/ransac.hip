@@ -56,6 +56,8 @@ struct RansacArgs {
     int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
     int mfma;     // 1: unsplit launches run the pre-test on the matrix cores (ransac_score_mfma_kernel)
     int mfKe;     // and scale the hypothesis side of num by 2^mfKe
+    uint4 *mfOps; // the correspondence side of that test, made once per call (see mfma_ops_start), or NULL: the
+                  // scoring kernel makes it from the fp32 records as it goes
     double maxSqErr;
     double successProb;
     int H;
@@ -905,12 +907,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
 // when this kernel may run (it exceeds the packed test's margin, which stays valid with it).
 //
 // A wave holds the operands of 16 T hypotheses in registers and walks the pair's correspondences 16 at a
-// time (operands made from the fp32 records while a chunk is staged).  Survivors -- (row, correspondence)
+// time.  The correspondence side is made once per call by ransac_mfma_ops_kernel (PRE; 128 B per correspondence,
+// read by the waves straight from global memory, no barrier in the loop: a wave that stops to evaluate its
+// survivors holds nobody up -- 17.8 -> 15.3 ms per 1024 pairs of the stress shape against staging through
+// LDS with a barrier per chunk) or, when there is no room for that table and in the entry point that allocates
+// nothing, by the block from the fp32 records while a chunk of 128 is staged in LDS.  Survivors -- (row, correspondence)
 // cells, < 0.1 % -- go to one queue per wave and are evaluated exactly 64 at a time, whichever rows they
 // belong to; the queue is first-in first-out and a row's cells enter it in correspondence order, so adding
 // the inliers' errors to their rows in queue order reproduces the sequential sum (RANSAC.cpp:207-221).
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 #define MF_CH 128 // correspondences staged per step (two threads make the operands of one: 256 threads, 2 sides)
 #define MF_SA 1024.0f
 #define MF_SB 16.0f
@@ -1020,7 +1028,41 @@ __device__ __forceinline__ void mfma_corr_operands(const RansacArgs &g, int side
     }
 }
 
-template <int T>
+// The correspondence side made once per call instead of once per block of rows.  A step of 16 correspondences
+// takes 2 KB: the 16 x 32 halves of num in fragment order ([K-octet][correspondence][8 halves]: 64 lanes read
+// 1 KB without a gap), then those of q.  First step of pair p (its correspondences start at row `base`):
+// regions of consecutive pairs do not overlap, each takes ceil(n / 16) steps.
+__host__ __device__ inline size_t mfma_ops_start(int64_t base, int p) { return (size_t)((base + 15 * (int64_t)p + 15) / 16); }
+
+// One thread per (correspondence slot, side); slots past the pair's last correspondence get zeros (d = 0).
+__global__ __launch_bounds__(256) void ransac_mfma_ops_kernel(const RansacArgs g)
+{
+    const int p = blockIdx.y;
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    const int slots = ((n + 15) >> 4) << 4;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int kk = t >> 1, side = t & 1;
+    if (kk >= slots) return;
+    _Float16 ob[32];
+    if (kk < n) {
+        const float *grp = g.rec32 + rec32_start(base, p) + (size_t)(kk >> 2) * 20 + (kk & 3);
+        mfma_corr_operands(g, side, grp[0], grp[4], grp[8], grp[12], grp[16], ob);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; i++) ob[i] = (_Float16)0.0f;
+    }
+    uint4 *dst = g.mfOps + (mfma_ops_start(base, p) + (size_t)(kk >> 4)) * 128 + side * 64 + (kk & 15);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        half8 a;
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = ob[8 * v + i];
+        *reinterpret_cast<half8 *>(dst + v * 16) = a;
+    }
+}
+
+template <int T, bool PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 : 3))) void ransac_score_mfma_kernel(const RansacArgs g)
 {
     constexpr int ROWS_W = 16 * T, ROWS_B = 4 * ROWS_W;
@@ -1034,12 +1076,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     _Float16 *opB = reinterpret_cast<_Float16 *>(smem);
     unsigned int *pool = reinterpret_cast<unsigned int *>(smem + OPB_HALVES * 2) + (threadIdx.x >> 6) * QCAP;
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
+    // Blocks go to the eight XCDs in turn.  All row blocks of a pair run on one of them (same residue mod 8),
+    // so that its L2 serves the pair's correspondences to all of them; the pairs past the last full group of
+    // eight take the plain order.
+    int p, rowBlock;
+    {
+        const int gx = (g.hEnd - g.hBegin + ROWS_B - 1) / ROWS_B, L = (int)blockIdx.x;
+        const int full = (g.nPairs >> 3) << 3;
+        if (L < full * gx) {
+            const int grp = L / (8 * gx), l = L - grp * 8 * gx;
+            p = grp * 8 + (l & 7);
+            rowBlock = l >> 3;
+        } else {
+            const int l = L - full * gx;
+            p = full + l / gx;
+            rowBlock = l - (l / gx) * gx;
+        }
+    }
     const int64_t base = g.corrOff[p];
     const int n = (int)(g.corrOff[p + 1] - base);
     if (!g.active[p]) return;
-    const int rowW0 = g.hBegin + (int)blockIdx.x * ROWS_B + wave * ROWS_W; // the wave's first row
+    const int rowW0 = g.hBegin + rowBlock * ROWS_B + wave * ROWS_W; // the wave's first row
     const int nRowsW = max(0, min(ROWS_W, g.hEnd - rowW0));
     const double *poseP = g.pose12 + (size_t)p * g.H * 12;
     double K[9];
@@ -1130,88 +1189,119 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    const float *rec32g = g.rec32 + rec32_start(base, p);
     unsigned hwId;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwId));
     unsigned turn = hwId & 3; // the waves of a SIMD take turns at the top priority (see ransac_score_kernel)
     const floatx4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    float recNext[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    auto fetch = [&](int kFirst) __attribute__((always_inline)) {
-        const int k = kFirst + (tid & (MF_CH - 1));
-        if (k < n) {
-            const float *grp = rec32g + (size_t)(k >> 2) * 20 + (k & 3);
+    // One step: the wave's 16 T rows against 16 correspondences (operands at opS: 1 KB for num, 1 KB for q;
+    // kStep = index of the first of them in the pair).
+    auto test_step = [&](const half8 bn, const half8 bq, int kStep) __attribute__((always_inline)) {
+        const int k = kStep + col;
+        floatx4 nu[T], qq[T];
 #pragma unroll
-            for (int f = 0; f < 5; f++) recNext[f] = grp[4 * f];
+        for (int t = 0; t < T; t++) {
+            nu[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(An[t], bn, zero, 0, 0, 0);
+            qq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[t], bq, zero, 0, 0, 0);
         }
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            // d = num^2 - q' per cell; no operand is inf or NaN, so neither is d
+            const f32x2 dA = __builtin_elementwise_fma(f32x2{nu[t][0], nu[t][1]}, f32x2{nu[t][0], nu[t][1]}, f32x2{qq[t][0], qq[t][1]});
+            const f32x2 dB = __builtin_elementwise_fma(f32x2{nu[t][2], nu[t][3]}, f32x2{nu[t][2], nu[t][3]}, f32x2{qq[t][2], qq[t][3]});
+            const float d[4] = {dA.x, dA.y, dB.x, dB.y};
+            const float least = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+            if (__builtin_amdgcn_fcmpf(least, 0.0f, 4) == 0) continue; // 4: ordered <
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool hit = d[r] < 0.0f;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask == 0) continue;
+                if (hit) {
+                    int at = qHead + qCount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (at >= QCAP) at -= QCAP;
+                    pool[at] = (unsigned)k | ((unsigned)(t * 16 + quad * 4 + r) << 24);
+                }
+                qCount += __builtin_popcountll(mask);
+            }
+        }
+        while (qCount >= 64) drain(64);
     };
-    fetch(0);
-    for (int k0 = 0; k0 < n; k0 += MF_CH) {
-        const int m = min(MF_CH, n - k0);
+    auto take_turn = [&]() __attribute__((always_inline)) {
         switch (turn++ & 3) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
         default: __builtin_amdgcn_s_setprio(3); break;
         }
-        { // stage: two threads per correspondence, one side each (zeros past the pair's last: d = 0)
-            const int kk = tid & (MF_CH - 1), side = tid >> 7; // (a wave makes one side: no divergence)
-            _Float16 ob[32];
-            if (kk < m) {
-                mfma_corr_operands(g, side, recNext[0], recNext[1], recNext[2], recNext[3], recNext[4], ob);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 32; i++) ob[i] = (_Float16)0.0f;
-            }
-            // fragment order: [step of 16][K-octet][correspondence of the step][8 halves] -- the 64 lanes of a
-            // fragment read (and the 64 of a write) cover 1 KB without a gap
-            _Float16 *dst = opB + side * (MF_CH * 32) + (kk >> 4) * 512 + (kk & 15) * 8;
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                half8 a;
-#pragma unroll
-                for (int i = 0; i < 8; i++) a[i] = ob[8 * v + i];
-                *reinterpret_cast<half8 *>(dst + v * 128) = a;
-            }
-        }
-        fetch(k0 + MF_CH); // the next chunk's records travel while this one is tested
-        __syncthreads();
+    };
+    if constexpr (PRE) {
+        // The prepared operands are in fragment order, so a wave reads its two fragments of a step straight from
+        // global memory (1 KB each, without a gap; the 64 waves that walk one pair share them through the caches),
+        // one step ahead.  No staging and no barrier: the waves of a block run on their own from here on.
         if (nRowsW > 0) {
-            const int steps = (m + 15) >> 4;
-            for (int s = 0; s < steps; s++) {
-                const half8 bn = *reinterpret_cast<const half8 *>(opB + s * 512 + lane * 8);
-                const half8 bq = *reinterpret_cast<const half8 *>(opB + MF_CH * 32 + s * 512 + lane * 8);
-                const int k = k0 + s * 16 + col;
-                floatx4 nu[T], qq[T];
-#pragma unroll
-                for (int t = 0; t < T; t++) {
-                    nu[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(An[t], bn, zero, 0, 0, 0);
-                    qq[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[t], bq, zero, 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < T; t++) {
-                    // d = num^2 - q' per cell; no operand is inf or NaN, so neither is d
-                    const f32x2 dA = __builtin_elementwise_fma(f32x2{nu[t][0], nu[t][1]}, f32x2{nu[t][0], nu[t][1]}, f32x2{qq[t][0], qq[t][1]});
-                    const f32x2 dB = __builtin_elementwise_fma(f32x2{nu[t][2], nu[t][3]}, f32x2{nu[t][2], nu[t][3]}, f32x2{qq[t][2], qq[t][3]});
-                    const float d[4] = {dA.x, dA.y, dB.x, dB.y};
-                    const float least = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-                    if (__builtin_amdgcn_fcmpf(least, 0.0f, 4) == 0) continue; // 4: ordered <
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool hit = d[r] < 0.0f;
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                        if (mask == 0) continue;
-                        if (hit) {
-                            int at = qHead + qCount + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                            if (at >= QCAP) at -= QCAP;
-                            pool[at] = (unsigned)k | ((unsigned)(t * 16 + quad * 4 + r) << 24);
-                        }
-                        qCount += __builtin_popcountll(mask);
-                    }
-                }
-                while (qCount >= 64) drain(64);
+            const int stepsPair = (n + 15) >> 4;
+            const half8 *opsL = reinterpret_cast<const half8 *>(g.mfOps + mfma_ops_start(base, p) * 128) + lane;
+            half8 bn = opsL[0], bq = opsL[64];
+            for (int s = 0; s < stepsPair; s++) {
+                const half8 *opN = opsL + (size_t)min(s + 1, stepsPair - 1) * 128;
+                const half8 bn2 = opN[0], bq2 = opN[64];
+                if ((s & 7) == 0) take_turn();
+                test_step(bn, bq, 16 * s);
+                bn = bn2;
+                bq = bq2;
             }
         }
-        __syncthreads();
+    } else {
+        const float *rec32g = g.rec32 + rec32_start(base, p);
+        float recNext[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        auto fetch = [&](int kFirst) __attribute__((always_inline)) {
+            const int k = kFirst + (tid & (MF_CH - 1));
+            if (k < n) {
+                const float *grp = rec32g + (size_t)(k >> 2) * 20 + (k & 3);
+#pragma unroll
+                for (int f = 0; f < 5; f++) recNext[f] = grp[4 * f];
+            }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < n; k0 += MF_CH) {
+            const int m = min(MF_CH, n - k0);
+            take_turn();
+            { // stage: two threads per correspondence, one side each (zeros past the pair's last: d = 0)
+                const int kk = tid & (MF_CH - 1), side = tid >> 7; // (a wave makes one side: no divergence)
+                _Float16 ob[32];
+                if (kk < m) {
+                    mfma_corr_operands(g, side, recNext[0], recNext[1], recNext[2], recNext[3], recNext[4], ob);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; i++) ob[i] = (_Float16)0.0f;
+                }
+                // fragment order: [step of 16][side][K-octet][correspondence of the step][8 halves] -- the 64 lanes
+                // of a fragment read (and the 64 of a write) cover 1 KB without a gap
+                _Float16 *dst = opB + (kk >> 4) * 1024 + side * 512 + (kk & 15) * 8;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    half8 a;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) a[i] = ob[8 * v + i];
+                    *reinterpret_cast<half8 *>(dst + v * 128) = a;
+                }
+            }
+            fetch(k0 + MF_CH); // the next chunk's records travel while this one is tested
+            __syncthreads();
+            if (nRowsW > 0) {
+                const int steps = (m + 15) >> 4;
+                const _Float16 *opC = opB + lane * 8;
+                half8 bn = *reinterpret_cast<const half8 *>(opC), bq = *reinterpret_cast<const half8 *>(opC + 512);
+                for (int s = 0; s < steps; s++) {
+                    const _Float16 *opN = opC + min(s + 1, steps - 1) * 1024;
+                    const half8 bn2 = *reinterpret_cast<const half8 *>(opN), bq2 = *reinterpret_cast<const half8 *>(opN + 512);
+                    test_step(bn, bq, k0 + s * 16);
+                    bn = bn2;
+                    bq = bq2;
+                }
+            }
+            __syncthreads();
+        }
     }
     if (qCount > 0) drain(qCount);
 #pragma unroll
@@ -1820,7 +1910,7 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, inlFlag, inlBlk, clock, packed;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, mfOps, inlFlag, inlBlk, clock, packed;
     PinBuf stage;   // single-pair calls: the winner's record and its inlier list in one copy
     PinBuf stageIn; // and the two correspondence arrays on their way in
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
@@ -1836,7 +1926,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
-                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->inlFlag, &b->inlBlk,
+                      &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->mfOps, &b->inlFlag, &b->inlBlk,
                       &b->clock, &b->packed};
     for (DevBuf *d : bufs) d->release();
     b->stage.release();
@@ -2013,6 +2103,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     }
     g.maxSqErr = maxSqErr;
     g.mfma = 0;
+    g.mfOps = nullptr;
     if (g.filter && ctx->ransac_mfma && maxSqErr > 0.0 && std::isfinite(maxSqErr)) {
         // scale of the hypothesis side: the largest entry of the q form, 2 c^2 (1/fx^2 + 1/fy^2) 2^(P-4) with
         // P = 2 (10 + mfKe), must stay inside fp16 (2^15 here)
@@ -2066,6 +2157,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         SFM_HIP(ctx, hipMemsetAsync(b->pose12.p, 0, (size_t)n_pairs * n_hyp * 12 * sizeof(double), st));
     if (!fit_only && total > 0)
         hipLaunchKernelGGL(ransac_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, total);
+    bool opsTried = false;
     for (int ph = 0; ph + 1 < nBounds; ph++) {
         g.hBegin = bounds[ph];
         g.hEnd = bounds[ph + 1];
@@ -2092,10 +2184,29 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                 score = Z > 1 ? ransac_score_kernel<SFM_LOSS_REPROJECTION, true, false>
                               : ransac_score_kernel<SFM_LOSS_REPROJECTION, false, false>;
             if (pretest && Z == 1 && g.mfma && loss == SFM_LOSS_REPROJECTION)
-                if (ctx->ransac_mfma == 2)
-                    hipLaunchKernelGGL(ransac_score_mfma_kernel<8>, dim3((rows + 511) / 512, n_pairs), dim3(256), 0, st, g);
-                else
-                    hipLaunchKernelGGL(ransac_score_mfma_kernel<4>, dim3((rows + 255) / 256, n_pairs), dim3(256), 0, st, g);
+            {
+                // The correspondence side of the test is made once per call (128 B per correspondence) when the
+                // table fits the budget; otherwise, and for the entry point that allocates nothing, every block
+                // makes it from the fp32 records as it goes.
+                const size_t opsBytes = (mfma_ops_start(total, n_pairs) + 1) * 2048;
+                if (!opsTried && !no_alloc && ctx->ransac_mfma_ops_gib > 0 && opsBytes <= ((size_t)ctx->ransac_mfma_ops_gib << 30)) {
+                    opsTried = true;
+                    if (b->mfOps.reserve(opsBytes) == hipSuccess) {
+                        g.mfOps = b->mfOps.as<uint4>();
+                        int64_t maxN = 0;
+                        for (int p = 0; p < n_pairs; p++) maxN = std::max(maxN, corr_offsets[p + 1] - corr_offsets[p]);
+                        const unsigned gxOps = (unsigned)((((maxN + 15) / 16) * 32 + 255) / 256);
+                        if (gxOps > 0) hipLaunchKernelGGL(ransac_mfma_ops_kernel, dim3(gxOps, n_pairs), dim3(256), 0, st, g);
+                    } else {
+                        (void)hipGetLastError(); // no room: the blocks make their operands
+                    }
+                }
+                const bool wide = ctx->ransac_mfma == 2;
+                const dim3 mgrid((unsigned)(((rows + (wide ? 511 : 255)) / (wide ? 512 : 256)) * n_pairs));
+                void (*mk)(const RansacArgs) = wide ? (g.mfOps ? ransac_score_mfma_kernel<8, true> : ransac_score_mfma_kernel<8, false>)
+                                                    : (g.mfOps ? ransac_score_mfma_kernel<4, true> : ransac_score_mfma_kernel<4, false>);
+                hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
+            }
             else
                 hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
             if (Z > 1) {

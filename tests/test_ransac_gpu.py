@@ -458,18 +458,65 @@ def test_matrix_core_pretest_is_bit_identical(ctx, oracle, ratio, thr, n, H):
     res = {}
     ctx.set_option("ransac_split", 0)
     try:
-        for name, flt, mf in (("mfma", 1, 1), ("packed", 1, 0), ("off", 0, 0)):
+        # mfma: the correspondence side of the test prepared once per call; mfma_blocks: made by every block
+        for name, flt, mf, gib in (("mfma", 1, 1, 64), ("mfma_blocks", 1, 1, 0), ("packed", 1, 0, 64), ("off", 0, 0, 64)):
             ctx.set_option("ransac_filter", flt)
             ctx.set_option("ransac_mfma", mf)
+            ctx.set_option("ransac_mfma_ops_gib", gib)
             res[name] = ctx.ransac_pair(x, y, tv["K"], S, max_sq_err=thr, adaptive=False)
     finally:
         ctx.set_option("ransac_split", 1)
         ctx.set_option("ransac_filter", 1)
         ctx.set_option("ransac_mfma", 1)
-    for other in ("packed", "off"):
+        ctx.set_option("ransac_mfma_ops_gib", 64)
+    for other in ("mfma_blocks", "packed", "off"):
         assert np.array_equal(res["mfma"]["counts"], res[other]["counts"]), other
         assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), res[other]["toterr"].view(np.uint64)), other
         assert np.array_equal(res["mfma"]["inliers"], res[other]["inliers"]), other
     exp = oracle.ransac(x, y, tv["K"], S, max_sq_err=thr, adaptive=False)
     assert np.array_equal(res["mfma"]["counts"], exp["counts"]) and np.array_equal(res["mfma"]["inliers"], exp["inliers"])
     assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), np.asarray(exp["toterr"]).view(np.uint64))
+
+
+def test_matrix_core_pretest_over_a_ragged_batch(ctx, oracle):
+    """A batch of pairs of unequal sizes (not multiples of the 16-correspondence steps or the 64-correspondence
+    chunks; more pairs than one group of eight, fewer than two, so that both block orders of the kernel run; an
+    empty pair and one below eight correspondences): prepared operands, operands made by the blocks and the packed
+    fp32 test give the same rows, and the winners are the restatement's."""
+    H = 520
+    sizes = [1000, 17, 0, 4097, 64, 5, 1023, 2500, 129, 3333, 16]
+    xs, ys, Ss, off = [], [], [], [0]
+    for k, n in enumerate(sizes):
+        tv = synth.two_view(max(n, 8), inlier_ratio=(0.15, 0.5, 0.8)[k % 3], seed=300 + k, noise_px=0.5)
+        xs.append(tv["x"][:n]); ys.append(tv["y"][:n])
+        Ss.append(synth.sample_table(max(n, 8), H, seed=400 + k) % max(n, 1))
+        off.append(off[-1] + n)
+    K = synth.default_K()
+    x, y, S = np.concatenate(xs), np.concatenate(ys), np.stack(Ss)
+    res = {}
+    ctx.set_option("ransac_split", 0)
+    try:
+        for name, mf, gib in (("prepared", 1, 64), ("blocks", 1, 0), ("packed", 0, 64)):
+            ctx.set_option("ransac_mfma", mf)
+            ctx.set_option("ransac_mfma_ops_gib", gib)
+            b = ctx.ransac_batch(np.array(off), x, y, K, S, H, max_sq_err=1.0, success_prob=0.999, adaptive=False)
+            res[name] = (b.best(), b.inliers())
+            b.close()
+    finally:
+        ctx.set_option("ransac_split", 1)
+        ctx.set_option("ransac_mfma", 1)
+        ctx.set_option("ransac_mfma_ops_gib", 64)
+    for other in ("blocks", "packed"):
+        for key in ("best_h", "count", "iterations"):
+            assert np.array_equal(res["prepared"][0][key], res[other][0][key]), (other, key)
+        assert np.array_equal(res["prepared"][0]["toterr"].view(np.uint64), res[other][0]["toterr"].view(np.uint64)), other
+        assert np.array_equal(res["prepared"][1][0], res[other][1][0]) and np.array_equal(res["prepared"][1][1], res[other][1][1]), other
+    best, (ioff, inl) = res["prepared"]
+    for k, n in enumerate(sizes):
+        if n < 8:
+            continue
+        e = oracle.ransac(x[off[k]:off[k + 1]], y[off[k]:off[k + 1]], K, S[k], max_sq_err=1.0, success_prob=0.999, adaptive=False)
+        assert best["best_h"][k] == e["best_h"], k
+        if e["best_h"] >= 0:
+            assert best["count"][k] == e["counts"][e["best_h"]], k
+        assert np.array_equal(inl[ioff[k]:ioff[k + 1]], e["inliers"]), k
