@@ -74,7 +74,14 @@ const char *sfm_version(void);
  * bound; 2..5 = ablations that give wrong results and exist for timing only),
  * "ransac_filter" (1 = skip evaluations the
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
- * everything; results are identical), "chain_table_entries" (entries of the
+ * everything; results are identical), "ransac_mfma" (1 = unsplit scoring
+ * launches run that pre-test on the matrix cores, default; 0 = on the vector
+ * ALU in packed fp32; 2 = matrix cores with 512 rows per block; results are
+ * identical), "ransac_mfma_ops_gib" (largest table of prepared matrix-core
+ * operands, 128 bytes per correspondence, that a RANSAC call may allocate, in
+ * GiB, default 64; 0 or a call that needs more = every block makes the
+ * operands of its correspondences as it goes; results are identical),
+ * "chain_table_entries" (entries of the
  * scale chain's (step, track) table, default 2^26; a sequence that needs more
  * goes through in windows of steps; results are identical), "hamming_mfma"
  * (1 = 256-bit binary descriptors are first matched on the matrix cores as
