@@ -512,6 +512,14 @@ def bench_pipeline(ctx, args):
     # the same tables in page-locked memory (sfm_host_alloc), where an adaptor that packs Keypoints can keep them
     qA, rA, qB, rB = (ctx.pinned_like(a) for a in (dA, pA, dB, pB))
     match_pinned_ms, _ = per_call_ms(lambda: ctx.match_pair(qA, rA, qB, rB, threshold=0.95, max_dist_sq=100.0 * 100.0))
+    # and as bytes (sfm_match_pair_u8): the synthetic SIFT-like tables hold integers in [0, 255], as OpenCV's do
+    match_u8_ms = None
+    if dA.size and dB.size and np.array_equal(dA, dA.astype(np.uint8)) and np.array_equal(dB, dB.astype(np.uint8)):
+        uA, uB = ctx.pinned_like(dA.astype(np.uint8)), ctx.pinned_like(dB.astype(np.uint8))
+        match_u8_ms, lst8 = per_call_ms(lambda: ctx.match_pair(uA, rA, uB, rB, threshold=0.95, max_dist_sq=100.0 * 100.0))
+        lst32 = ctx.match_pair(qA, rA, qB, rB, threshold=0.95, max_dist_sq=100.0 * 100.0)
+        assert np.array_equal(lst8, lst32), "byte tables and float tables must give one list"
+        del uA, uB
     del qA, rA, qB, rB
     ctx.set_option("ransac_seed", 20261111)
     ransac_call_ms, rr = per_call_ms(lambda: ctx.ransac_pair(x0, y0, K, H, max_sq_err=1.0, success_prob=0.999, adaptive=True,
@@ -531,6 +539,7 @@ def bench_pipeline(ctx, args):
                     "(pageable unless said otherwise), lists out; upload, ingest and download inside the time; mean of 30 "
                     "calls, best of three rounds after ten untimed calls",
             "match_pair_ms": round(match_call_ms, 3), "match_pair_ms_tables_in_page_locked_memory": round(match_pinned_ms, 3),
+            "match_pair_ms_byte_tables_in_page_locked_memory": None if match_u8_ms is None else round(match_u8_ms, 3),
             "features": int(counts[0]),
             "ransac_pair_ms": round(ransac_call_ms, 3), "correspondences": int(len(x0)), "hypotheses": H,
             "ransac_iterations": int(rr["iterations"]), "ransac_inliers": int(len(rr["inliers"])),

@@ -148,6 +148,20 @@ int sfm_match_pair(sfm_ctx *ctx, int algorithm,
                    int32_t *pairs_out, int capacity, int *count_out,
                    int32_t *matches1_out, int32_t *matches2_out);
 
+/* The same call for byte-valued descriptors: descA / descB hold one byte per
+ * element (nA x dim, nB x dim).  OpenCV's SIFT delivers integers in [0, 255]
+ * that the reference stores as floats (submodules/detect/detectOpenCv.cpp:166-169);
+ * an adaptor that sees only such values while it packs the Keypoint vectors
+ * (match.hpp:49-53) can hand them over as bytes: a quarter of the upload, and
+ * the widened bytes are the same float values, so the results are those of
+ * sfm_match_pair on the float tables, bit for bit. */
+int sfm_match_pair_u8(sfm_ctx *ctx, int algorithm,
+                      const uint8_t *descA, const double *ptsA, int nA,
+                      const uint8_t *descB, const double *ptsB, int nB, int dim,
+                      int metric, float threshold, float max_distance_px_squared,
+                      int32_t *pairs_out, int capacity, int *count_out,
+                      int32_t *matches1_out, int32_t *matches2_out);
+
 /* ---- matching: resident image table + pair list ----------------------------
  * The batch form of the same function, for many pairs over one image set
  * (the reference calls match() once per consecutive frame pair,

@@ -27,7 +27,7 @@ _STATUS_NAMES = {1: "invalid argument", 2: "no gfx950 device", 3: "out of memory
 EXPORTED_SYMBOLS = [
     "sfm_ctx_create", "sfm_ctx_destroy", "sfm_ctx_synchronize", "sfm_last_error", "sfm_version",
     "sfm_ctx_set_option", "sfm_ctx_last_kernel_ms", "sfm_host_alloc", "sfm_host_free",
-    "sfm_match_pair", "sfm_imageset_create", "sfm_imageset_create_u8", "sfm_imageset_create_device", "sfm_imageset_destroy",
+    "sfm_match_pair", "sfm_match_pair_u8", "sfm_imageset_create", "sfm_imageset_create_u8", "sfm_imageset_create_device", "sfm_imageset_destroy",
     "sfm_imageset_device_bytes", "sfm_match_batch", "sfm_match_result_total", "sfm_match_result_offsets",
     "sfm_match_result_pairs", "sfm_match_result_device", "sfm_match_result_stats", "sfm_match_result_stats_ex",
     "sfm_match_result_device_bytes",
@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
     L.sfm_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
     L.sfm_ctx_last_kernel_ms.argtypes = [vp, i32, P(f64), P(i32)]
     L.sfm_match_pair.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, i32, P(i32), vp, vp]
+    L.sfm_match_pair_u8.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, f32, f32, vp, i32, P(i32), vp, vp]
     L.sfm_imageset_create.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
     L.sfm_imageset_create_device.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
     L.sfm_imageset_create_u8.argtypes = [vp, i32, vp, vp, vp, i32, P(vp)]
@@ -402,8 +403,11 @@ class Context:
     # ---- matching -------------------------------------------------------------------------
     def match_pair(self, descA, ptsA, descB, ptsB, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE,
                    algorithm=MATCH_TWO_SIDED, return_best=False):
-        descA = np.ascontiguousarray(descA, np.float32)
-        descB = np.ascontiguousarray(descB, np.float32)
+        """SfM::match::match for one pair.  Tables of dtype uint8 (both) go through sfm_match_pair_u8."""
+        descA, descB = np.asarray(descA), np.asarray(descB)
+        as_bytes = descA.dtype == np.uint8 and descB.dtype == np.uint8
+        descA = np.ascontiguousarray(descA, np.uint8 if as_bytes else np.float32)
+        descB = np.ascontiguousarray(descB, np.uint8 if as_bytes else np.float32)
         ptsA = np.ascontiguousarray(ptsA, np.float64).reshape(-1, 2)
         ptsB = np.ascontiguousarray(ptsB, np.float64).reshape(-1, 2)
         nA, nB = len(ptsA), len(ptsB)
@@ -413,9 +417,10 @@ class Context:
         m1 = np.full(max(nA, 1), -1, np.int32)
         m2 = np.full(max(nB, 1), -1, np.int32)
         cnt = C.c_int(0)
-        self.check(lib().sfm_match_pair(self._h, algorithm, _ptr(descA), _ptr(ptsA), nA, _ptr(descB), _ptr(ptsB),
-                                        nB, dim, metric, threshold, max_dist_sq, _ptr(pairs), cap,
-                                        C.byref(cnt), _ptr(m1), _ptr(m2)))
+        call = lib().sfm_match_pair_u8 if as_bytes else lib().sfm_match_pair
+        self.check(call(self._h, algorithm, _ptr(descA), _ptr(ptsA), nA, _ptr(descB), _ptr(ptsB),
+                        nB, dim, metric, threshold, max_dist_sq, _ptr(pairs), cap,
+                        C.byref(cnt), _ptr(m1), _ptr(m2)))
         out = pairs[:cnt.value].copy()
         if return_best:
             return out, m1[:nA].copy(), m2[:nB].copy()

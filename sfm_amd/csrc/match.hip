@@ -1318,6 +1318,7 @@ extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
 struct TwoParts {
     const float *desc[2];
     const double *pts[2];
+    const unsigned char *desc_u8[2] = {nullptr, nullptr}; // byte-valued tables instead of desc (both or neither)
 };
 
 // reuse: slot holding a set built earlier by this function from host tables, whose device buffers are
@@ -1379,6 +1380,7 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
 
     const size_t b32 = (size_t)r32 * dim * sizeof(float);
     const size_t bpts = (size_t)r32 * 2 * sizeof(double);
+    const bool parts_u8 = parts && (parts->desc_u8[0] || parts->desc_u8[1]);
     if (on_device) {
         s->owns_desc32 = false;
         s->owns_pts = false;
@@ -1398,15 +1400,25 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
             tmp.release();
         } else if (parts) {
             int64_t row = 0;
+            if (parts_u8) SET_HIP(s->desc8u.reserve((size_t)(r32 ? r32 : 1) * dim));
             for (int k = 0; k < 2 && k < n_images; k++) {
                 const size_t nk = (size_t)counts[k];
                 if (nk) {
+                    if (parts_u8) // a quarter of the bytes; widened below
+                        SET_HIP(hipMemcpyAsync(s->desc8u.as<unsigned char>() + (size_t)row * dim, parts->desc_u8[k], nk * dim,
+                                               hipMemcpyHostToDevice, ctx->stream));
+                    else
                     SET_HIP(hipMemcpyAsync(s->desc32.as<float>() + (size_t)row * dim, parts->desc[k], nk * dim * sizeof(float),
                                            hipMemcpyHostToDevice, ctx->stream));
                     SET_HIP(hipMemcpyAsync(s->pts.as<double>() + (size_t)row * 2, parts->pts[k], nk * 2 * sizeof(double),
                                            hipMemcpyHostToDevice, ctx->stream));
                 }
                 row += counts[k];
+            }
+            if (parts_u8 && r32 > 0) {
+                const int64_t n = r32 * dim;
+                hipLaunchKernelGGL(expand_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const unsigned char *)s->desc8u.p, n, s->desc32.as<float>());
             }
         } else if (b32)
             SET_HIP(hipMemcpyAsync(s->desc32.p, desc, b32, hipMemcpyHostToDevice, ctx->stream));
@@ -1447,9 +1459,13 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     }
     s->flags_on_host = !no_wait;
     // byte copy for the exact pass when the whole table is byte-valued
+    // (tables that came as bytes are their own byte copy: with 128 elements per row the upload has its layout)
+    const bool bytes_in_place = parts_u8 && dim == 128 && r32 > 0;
     s->u8_exact = dim == 128 && r32 > 0 && !no_wait;
     for (int i = 0; i < n_images; i++) s->u8_exact = s->u8_exact && !(s->flags[i] & IMG_NOT_U8);
-    if (s->u8_exact) {
+    if (bytes_in_place) {
+        s->u8_exact = true;
+    } else if (s->u8_exact) {
         SET_HIP(s->desc8u.reserve((size_t)r32 * 128));
         hipLaunchKernelGGL(ingest_u8_kernel, dim3((unsigned)((r32 * 8 + 255) / 256)), dim3(256), 0, ctx->stream,
                            s->desc32.as<float>(), r32, s->desc8u.as<unsigned char>());
@@ -2112,10 +2128,10 @@ extern "C" int sfm_match_result_stats(sfm_match_result *res, int64_t *candidates
     return SFM_OK;
 }
 
-extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, const double *ptsA, int nA,
-                              const float *descB, const double *ptsB, int nB, int dim, int metric,
-                              float threshold, float max_distance_px_squared, int32_t *pairs_out, int capacity,
-                              int *count_out, int32_t *matches1_out, int32_t *matches2_out)
+static int match_pair_impl(sfm_ctx *ctx, int algorithm, const void *descA, const double *ptsA, int nA, const void *descB,
+                           const double *ptsB, int nB, bool bytes, int dim, int metric, float threshold,
+                           float max_distance_px_squared, int32_t *pairs_out, int capacity, int *count_out,
+                           int32_t *matches1_out, int32_t *matches2_out)
 {
     if (!ctx || !count_out) return SFM_ERR_INVALID_ARG;
     *count_out = 0;
@@ -2128,7 +2144,15 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
     // two-image set: A then B.  The set and the result live in the context from call to call, so a
     // sequence of calls (the reference matches frame after frame) allocates once.
     const int32_t counts[2] = {nA, nB};
-    const TwoParts parts = {{descA, descB}, {ptsA, ptsB}};
+    TwoParts parts = {{nullptr, nullptr}, {ptsA, ptsB}};
+    if (bytes) {
+        static const unsigned char none = 0; // (an empty image still marks the pair as byte-valued)
+        parts.desc_u8[0] = descA ? static_cast<const unsigned char *>(descA) : &none;
+        parts.desc_u8[1] = descB ? static_cast<const unsigned char *>(descB) : &none;
+    } else {
+        parts.desc[0] = static_cast<const float *>(descA);
+        parts.desc[1] = static_cast<const float *>(descB);
+    }
     sfm_imageset *set = nullptr;
     // Nothing waits for the device between the upload and the copy of the results: the set is built without
     // its host-side flags, and the result kept in the context is idle because every call ends with a wait.
@@ -2164,6 +2188,24 @@ extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, c
     if (b2) memcpy(matches2_out, stage + 16 + (size_t)nA * sizeof(int32_t), b2);
     *count_out = (int)total;
     return SFM_OK;
+}
+
+extern "C" int sfm_match_pair(sfm_ctx *ctx, int algorithm, const float *descA, const double *ptsA, int nA,
+                              const float *descB, const double *ptsB, int nB, int dim, int metric,
+                              float threshold, float max_distance_px_squared, int32_t *pairs_out, int capacity,
+                              int *count_out, int32_t *matches1_out, int32_t *matches2_out)
+{
+    return match_pair_impl(ctx, algorithm, descA, ptsA, nA, descB, ptsB, nB, false, dim, metric, threshold, max_distance_px_squared,
+                           pairs_out, capacity, count_out, matches1_out, matches2_out);
+}
+
+extern "C" int sfm_match_pair_u8(sfm_ctx *ctx, int algorithm, const uint8_t *descA, const double *ptsA, int nA,
+                                 const uint8_t *descB, const double *ptsB, int nB, int dim, int metric,
+                                 float threshold, float max_distance_px_squared, int32_t *pairs_out, int capacity,
+                                 int *count_out, int32_t *matches1_out, int32_t *matches2_out)
+{
+    return match_pair_impl(ctx, algorithm, descA, ptsA, nA, descB, ptsB, nB, true, dim, metric, threshold, max_distance_px_squared,
+                           pairs_out, capacity, count_out, matches1_out, matches2_out);
 }
 
 void sfm_pair_match_free(sfm_ctx *ctx)

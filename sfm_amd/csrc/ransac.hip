@@ -1238,8 +1238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 
         // The prepared operands are in fragment order, so a wave reads its two fragments of a step straight from
         // global memory (1 KB each, without a gap; the 64 waves that walk one pair share them through the caches),
         // one step ahead.  No staging and no barrier: the waves of a block run on their own from here on.
-        if (nRowsW > 0) {
-            const int stepsPair = (n + 15) >> 4;
+        const int stepsPair = (n + 15) >> 4;
+        if (nRowsW > 0 && stepsPair > 0) {
             const half8 *opsL = reinterpret_cast<const half8 *>(g.mfOps + mfma_ops_start(base, p) * 128) + lane;
             half8 bn = opsL[0], bq = opsL[64];
             for (int s = 0; s < stepsPair; s++) {

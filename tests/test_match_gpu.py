@@ -508,3 +508,28 @@ def test_two_phase_sweeps_and_the_gate(ctx, oracle, thr):
     assert res.stats_ex()[2] == 2, "both pairs were meant to need the filtered passes"
     res.close()
     s.close()
+
+
+def test_byte_tables_through_the_pair_call(ctx, oracle):
+    """sfm_match_pair_u8: descriptors handed over as bytes (OpenCV's SIFT, detectOpenCv.cpp:166-169) give the
+    lists and bests of the float call and of the restatement, bit for bit -- for 128 elements per row (the bytes
+    serve the exact pass as they are) and for other lengths, for both metrics, thresholds that flood the bound
+    passes, empty images, and between float calls on the same context."""
+    rng = np.random.default_rng(321)
+    cases = [(900, 700, 128, 0.9, 0), (50, 1300, 128, 0.5, 0), (1300, 40, 64, 0.9, 0), (0, 10, 128, 0.9, 0), (10, 0, 128, 0.9, 0),
+             (2048, 2048, 128, 0.95, 0), (300, 300, 7, 0.8, 0), (700, 900, 128, 1e5, 1), (400, 400, 128, 0.0, 0)]
+    for nA, nB, dim, thr, metric in cases:
+        base = rng.integers(0, 256, size=(max(nA, nB, 1), dim)).astype(np.uint8)
+        A = base[:nA].copy()
+        B = base[:nB][::-1].copy()
+        if nB:
+            B[::3] = rng.integers(0, 256, size=B[::3].shape)  # a third of the rows unrelated
+        pA, pB = rng.uniform(0, 100, size=(nA, 2)), rng.uniform(0, 100, size=(nB, 2))
+        got, m1, m2 = ctx.match_pair(A, pA, B, pB, threshold=thr, max_dist_sq=1e8, metric=metric, return_best=True)
+        flt, f1, f2 = ctx.match_pair(A.astype(np.float32), pA, B.astype(np.float32), pB, threshold=thr, max_dist_sq=1e8,
+                                     metric=metric, return_best=True)
+        exp, e1, e2 = oracle.match(A.astype(np.float32), pA, B.astype(np.float32), pB, threshold=thr, max_dist_sq=1e8, metric=metric)
+        assert np.array_equal(got, exp) and np.array_equal(m1, e1) and np.array_equal(m2, e2), (nA, nB, dim, thr)
+        assert np.array_equal(flt, exp) and np.array_equal(f1, e1) and np.array_equal(f2, e2), (nA, nB, dim, thr)
+    with pytest.raises(capi.SfmError):
+        ctx.match_pair(np.zeros((4, 200), np.uint8), np.zeros((4, 2)), np.zeros((4, 200), np.uint8), np.zeros((4, 2)))
