@@ -588,7 +588,7 @@ def ransac_valu_profile(mfma):
     shape, from the committed counter pass of the kernel that runs (static; None if the file is absent).
     Returns (instructions, correspondences per group, extra fields, source)."""
     if mfma:
-        path = os.path.join(ROOT, "profiles", "r2c_pmc_sq_ransac_mfma.json")
+        path = os.path.join(ROOT, "profiles", "r2e_pmc_sq_ransac_mfma.json")
         if os.path.exists(path):
             with open(path) as f:
                 t = json.load(f)
@@ -600,7 +600,7 @@ def ransac_valu_profile(mfma):
                              "matrix_pipe_busy_fraction_of_simd_cycles_under_counters": round(v["mfma_busy_fraction_of_simd_cycles"], 4),
                              "valu_busy_fraction_of_simd_cycles_under_counters": round(v["valu_busy_fraction_of_simd_cycles"], 4),
                              "clock_GHz_under_counters": round(v["clock_GHz_under_load"], 3)}
-                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/r2c_pmc_sq_ransac_mfma.json"
+                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/r2e_pmc_sq_ransac_mfma.json"
         return None, None, None, None
     for name in ("r2_pmc_sq_ransac.json", "r1_final4_pmc_sq_ransac.json"):
         path = os.path.join(ROOT, "profiles", name)

@@ -76,8 +76,7 @@ const char *sfm_version(void);
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
  * everything; results are identical), "ransac_mfma" (1 = unsplit scoring
  * launches run that pre-test on the matrix cores, default; 0 = on the vector
- * ALU in packed fp32; 2 = matrix cores with 512 rows per block; results are
- * identical), "ransac_mfma_ops_gib" (largest table of prepared matrix-core
+ * ALU in packed fp32; results are identical), "ransac_mfma_ops_gib" (largest table of prepared matrix-core
  * operands, 128 bytes per correspondence, that a RANSAC call may allocate, in
  * GiB, default 64; 0 or a call that needs more = every block makes the
  * operands of its correspondences as it goes; results are identical),

@@ -1,7 +1,7 @@
 # Per-kernel durations of the RANSAC stress shape (1024 pairs) for variants of the matrix-core pre-test:
-# prepared operands (default), operands made by the blocks (SFM_RANSAC_MFMA_OPS_GIB=0), wide blocks (SFM_RANSAC_MFMA=2).
+# prepared operands (default), operands made by the blocks (SFM_RANSAC_MFMA_OPS_GIB=0), packed fp32 test (SFM_RANSAC_MFMA=0).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for v in ${VARIANTS:-1:64 1:0 2:64}; do
+for v in ${VARIANTS:-1:64 1:0 0:64}; do
   set -- ${v/:/ }
   tag=m$1_g$2
   rm -rf gpurun_out/trab_$tag

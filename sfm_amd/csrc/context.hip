@@ -129,7 +129,7 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "ransac_filter")) {
         ctx->ransac_filter = value != 0;
     } else if (!strcmp(key, "ransac_mfma")) {
-        ctx->ransac_mfma = (int)value;
+        ctx->ransac_mfma = value != 0;
     } else if (!strcmp(key, "ransac_mfma_ops_gib")) {
         if (value < 0 || value > 4096) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac_mfma_ops_gib must be in [0, 4096]");
         ctx->ransac_mfma_ops_gib = (int)value;

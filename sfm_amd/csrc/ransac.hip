@@ -1063,19 +1063,28 @@ __global__ __launch_bounds__(256) void ransac_mfma_ops_kernel(const RansacArgs g
 }
 
 template <int T, bool PRE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 : 3))) void ransac_score_mfma_kernel(const RansacArgs g)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ransac_score_mfma_kernel(const RansacArgs g)
 {
     constexpr int ROWS_W = 16 * T, ROWS_B = 4 * ROWS_W;
-    static_assert(T % 4 == 0 && T <= 8, "a lane owns T / 4 rows of its wave");
+    static_assert(T == 4, "a lane owns T / 4 rows of its wave; eight tiles per wave (three waves per SIMD) measured slower");
     // One drain site per step: the queue must take what a step can add (every cell of the wave's T tiles) on
     // top of what a drain leaves (< 64).
     constexpr int QCAP = 64 + T * 256;
     constexpr int OPB_HALVES = 2 * MF_CH * 32; // num side, then q side
     constexpr int SLICE_HALVES = 4 * 64 * 64;  // the hypothesis operands on their way into fragments
-    constexpr int SMEM_BYTES = (OPB_HALVES * 2 + 4 * QCAP * 4) > SLICE_HALVES * 2 ? (OPB_HALVES * 2 + 4 * QCAP * 4) : SLICE_HALVES * 2;
+    // per wave, behind the queues: the errors of the 64 entries of a drain, and per row of the wave the lanes
+    // whose entries are inliers of that row (one bit per lane)
+    constexpr int ACC_BYTES = 64 * 8 + ROWS_W * 8;
+    constexpr int ACC_AT = OPB_HALVES * 2 + 4 * QCAP * 4;
+    static_assert(ACC_AT >= SLICE_HALVES * 2 && ACC_AT % 8 == 0, "the row masks are cleared before the set-up uses its slices");
+    constexpr int SMEM_BYTES = ACC_AT + 4 * ACC_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     _Float16 *opB = reinterpret_cast<_Float16 *>(smem);
     unsigned int *pool = reinterpret_cast<unsigned int *>(smem + OPB_HALVES * 2) + (threadIdx.x >> 6) * QCAP;
+    double *accE = reinterpret_cast<double *>(smem + ACC_AT + (threadIdx.x >> 6) * ACC_BYTES);
+    unsigned long long *accM = reinterpret_cast<unsigned long long *>(accE + 64);
+#pragma unroll
+    for (int i = 0; i < T / 4; i++) accM[i * 64 + (threadIdx.x & 63)] = 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
     // Blocks go to the eight XCDs in turn.  All row blocks of a pair run on one of them (same residue mod 8),
@@ -1168,20 +1177,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T == 4 ? 4 
         if (qHead >= QCAP) qHead -= QCAP;
         qCount -= take;
         // inliers in queue order, each added to its row (lane hl % 64 keeps the sums of rows hl, hl + 64)
-        unsigned long long m = __builtin_amdgcn_ballot_w64(inl);
-        const int elo = __double2loint(e), ehi = __double2hiint(e);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int h1 = __builtin_amdgcn_readlane(hl, l);
-            const double e1 = __hiloint2double(__builtin_amdgcn_readlane(ehi, l), __builtin_amdgcn_readlane(elo, l));
-            if (lane == (h1 & 63)) {
+        // Inliers are added to their rows in queue order (lane order here).  Rows are independent of each
+        // other: every entry marks its lane in its row's mask, and the lane that keeps a row's sum walks that
+        // mask from the lowest lane up, so the rows' chains of additions run side by side (with most cells
+        // inliers a drain holds 16 entries of each of 4 rows: 16 rounds instead of 64).
+        if (__builtin_amdgcn_ballot_w64(inl) != 0) {
+            accE[lane] = e;
+            if (inl) atomicOr(reinterpret_cast<unsigned int *>(accM) + 2 * hl + (lane >> 5), 1u << (lane & 31));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int i = 0; i < T / 4; i++)
-                    if ((h1 >> 6) == i) {
+            for (int i = 0; i < T / 4; i++) {
+                unsigned long long mk = accM[i * 64 + lane];
+                if (mk) accM[i * 64 + lane] = 0ull;
+                while (__builtin_amdgcn_ballot_w64(mk != 0ull) != 0) {
+                    if (mk) {
+                        const int l = __builtin_ctzll(mk);
+                        mk &= mk - 1;
                         count[i]++;
-                        tot[i] += e1;
+                        tot[i] += accE[l];
                     }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2201,10 +2218,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                         (void)hipGetLastError(); // no room: the blocks make their operands
                     }
                 }
-                const bool wide = ctx->ransac_mfma == 2;
-                const dim3 mgrid((unsigned)(((rows + (wide ? 511 : 255)) / (wide ? 512 : 256)) * n_pairs));
-                void (*mk)(const RansacArgs) = wide ? (g.mfOps ? ransac_score_mfma_kernel<8, true> : ransac_score_mfma_kernel<8, false>)
-                                                    : (g.mfOps ? ransac_score_mfma_kernel<4, true> : ransac_score_mfma_kernel<4, false>);
+                const dim3 mgrid((unsigned)(((rows + 255) / 256) * n_pairs));
+                void (*mk)(const RansacArgs) = g.mfOps ? ransac_score_mfma_kernel<4, true> : ransac_score_mfma_kernel<4, false>;
                 hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
             }
             else

@@ -37,7 +37,7 @@ def test_random_case(ctx, oracle, seed):
     # operands or with operands made by the blocks (unsplit launches only), split over correspondences or not.
     ctx.set_option("ransac_filter", int(rng.integers(2)))
     ctx.set_option("ransac_split", int(rng.integers(2)))
-    ctx.set_option("ransac_mfma", int(rng.integers(3)))
+    ctx.set_option("ransac_mfma", int(rng.integers(2)))
     ctx.set_option("ransac_mfma_ops_gib", int(rng.choice([0, 64])))
     try:
         got = ctx.ransac_pair(x, y, K, S, max_sq_err=thr, success_prob=0.999, adaptive=adaptive)
@@ -81,7 +81,7 @@ def test_random_batch(ctx, oracle, seed):
         off.append(off[-1] + n)
     x, y, S = np.concatenate(xs), np.concatenate(ys), np.stack(Ss)
     ctx.set_option("ransac_split", int(rng.integers(2)))
-    ctx.set_option("ransac_mfma", int(rng.integers(3)))
+    ctx.set_option("ransac_mfma", int(rng.integers(2)))
     ctx.set_option("ransac_mfma_ops_gib", int(rng.choice([0, 64])))
     try:
         b = ctx.ransac_batch(np.array(off), x, y, K, S, H, max_sq_err=thr, success_prob=0.999, adaptive=adaptive)
