@@ -364,7 +364,7 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     head = np.ascontiguousarray(pair_list[:min(len(pair_list), 4096)])
     rows.append(row("the headline's images", imgset, head, args.threshold, "fp16",
                     "fp16 bound instead of int8: half the MFMA rate, a margin of 1.5e-3 instead of 2-4e-2"))
-    loose = np.ascontiguousarray(pair_list[:min(len(pair_list), 256)])
+    loose = np.ascontiguousarray(pair_list[:min(len(pair_list), 1024)])
     rows.append(row("the headline's images", imgset, loose, 0.5, "int8",
                     "the reference's default threshold: nearly every cell passes, lists overflow, both filtered sweeps run"))
     n_img = 40
@@ -373,7 +373,7 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     s = ctx.imageset(c, d, p)
     rows.append(row(f"{n_img} images x {n} Gaussian float descriptors (sigma 1; shared features re-detected with noise 0.05)",
                     s, pl, args.threshold, "int8", "general floats: exact pass reads the fp32 table"))
-    rows.append(row(f"{n_img} images x {n} Gaussian float descriptors", s, np.ascontiguousarray(pl[:128]), 0.5, "int8",
+    rows.append(row(f"{n_img} images x {n} Gaussian float descriptors", s, pl, 0.5, "int8",
                     "unrelated Gaussian descriptors have cosine ~ N(0, 1/128): 0.5 is still selective"))
     s.close()
     rng = np.random.default_rng(7)
@@ -385,7 +385,7 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     pts = rng.uniform(0, 4000, (n_img * n, 2))
     s = ctx.imageset(np.full(n_img, n, np.int32), hard, pts)
     rows.append(row(f"{n_img} images x {n} SIFT-like descriptors with a common part: unrelated cosines ~0.93", s,
-                    np.ascontiguousarray(pl[:256]), args.threshold, "int8",
+                    pl, args.threshold, "int8",
                     "the int8 margin admits the unrelated cells, lists flood, the fp16 bound redoes every pair"))
     s.close()
     return rows
