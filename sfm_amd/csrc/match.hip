@@ -746,11 +746,14 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // candidate test.
 // MODE (fp16 strict instances only): the two-phase form of the filtered passes, for pairs whose pixel gate
 // excludes nothing.  A row's best cell is then its best over all columns, so
-//   1 = a sweep that only records every row's largest approximate cosine (no candidates), and
-//   2 = a strict sweep whose accumulators start at minus the row's bar, max(that maximum - 2 margins, the
-//       pair's bound): what stays positive is within reach of the row's best and is queued.
-// Both run once with each image in the register-resident role, like the filtered pass they replace, which
-// has to carry running bounds and pixel positions along and queues the harmonic number of cells per row.
+//   1 = a sweep that only finds every row's largest approximate cosine (no candidates) and leaves the row's bar,
+//       max(that maximum - 2 margins, the pair's bound); it runs once with each image in the register-resident
+//       role, so that the rows of both images have bars; and
+//   2 = one strict sweep whose accumulators start at minus the lower of the cell's two bars (its row's, in
+//       registers; its column's, staged beside the column's descriptors): what stays positive is within reach
+//       of its row's best or of its column's best and is queued.
+// They replace the filtered pass, which has to carry running bounds and pixel positions along, queues the
+// harmonic number of cells per row, and runs twice.
 template <int FORM, bool DOT, bool GENERAL, int ABL, int MODE = 0>
 __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem)
 {
@@ -769,6 +772,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     __shared__ double2 ptsRow[GENERAL ? SIM_BLOCK_ROWS : 1];
     __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? SIM_BN : 1];
     __shared__ unsigned rowBound[GENERAL ? SIM_BLOCK_ROWS : 1];
+    __shared__ float colBar[MODE == 2 ? 2 : 1][MODE == 2 ? SIM_BN : 1]; // minus the bars of the staged columns
 
     const int2 w = g.work[workItem];
     if (w.x < 0) return;
@@ -839,6 +843,12 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
                 __builtin_amdgcn_global_load_lds((gptr_t)(g.pts + pr.rowB32 + j), (lptr_t)&ptsCol[buf][0], 16, 0, 0);
             }
         }
+        if constexpr (MODE == 2) { // the step's 64 column bars (minus the bar, as the first sweeps left them): one instruction
+            if (wave == 0) {
+                const int j = min(c * SIM_BN + lane, pr.nB - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(g.rowMax + pr.bestCol + j), (lptr_t)&colBar[buf][0], 4, 0, 0);
+            }
+        }
     };
     if constexpr (GENERAL) {
         for (int rr = tid; rr < SIM_BLOCK_ROWS; rr += SIM_WAVES * 64) {
@@ -862,28 +872,23 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = rowBase + 16 * t + 4 * (lane >> 4) + q;
-                // The row's best exact cosine is within one margin of its approximation, which is therefore at
-                // least the largest approximation minus two margins; 1e-5 more pays for the rounding of the
-                // accumulators (they start at the bar instead of zero).  A row without a finite maximum (NaNs
-                // only) gets no bar, a row beyond the image queues nothing.
-                float bar = INFINITY;
-                if (i < pr.nA) {
-                    const float mx = g.rowMax[pr.bestRow + i];
-                    bar = fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
-                    if (!(mx == mx)) bar = pr.thr_m;
-                }
-                rowVal[t][q] = -bar;
+                // Minus the row's bar, as the first sweep left it (see there); a row beyond the image queues nothing.
+                rowVal[t][q] = i < pr.nA ? g.rowMax[pr.bestRow + i] : -INFINITY;
             }
     }
     // one 32-column step: column tile ct, k-block s: one B fragment from LDS feeds four MFMAs
     auto mfma_step = [&](AccT &acc, int buf, int sub) __attribute__((always_inline)) {
         if constexpr (MODE == 2) {
+            // A cell matters when it can be its row's best or its column's best: it starts at minus the lower of
+            // the two bars.
 #pragma unroll
-            for (int c = 0; c < 2; c++)
+            for (int c = 0; c < 2; c++) {
+                const float nb = colBar[buf][sub * 32 + c * 16 + (lane & 15)];
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc.a[c][t][q] = rowVal[t][q];
+                    for (int q = 0; q < 4; q++) acc.a[c][t][q] = fmaxf(rowVal[t][q], nb);
+            }
         } else {
             acc.zero();
         }
@@ -913,8 +918,12 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
     WaveQueue wq;
     wq.abl = ABL;
-    wq.cap = g.candCap / nQueues;
-    wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * wq.cap;
+    // (The sweep against the bars of both images runs in one orientation only: its waves share out all slices of
+    // the pair, S consecutive ones each, and fill them as one list.)
+    const int sliceCap = g.candCap / nQueues;
+    const int S = MODE == 2 ? nQueues / nQ0 : 1;
+    wq.cap = sliceCap * S;
+    wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * S * sliceCap;
     wq.n = 0;
     if (MODE == 2 && !(thr_m > -INFINITY)) wq.n = wq.cap + 1; // norms out of range: no bound holds, the pair is scored cell by cell
     auto test = [&](const AccT &acc, int colBase, int buf) __attribute__((always_inline)) {
@@ -976,12 +985,26 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 #pragma unroll
                 for (int d = 1; d < 16; d <<= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
                 const int i = rowBase + 16 * t + 4 * (lane >> 4) + q;
-                if ((lane & 15) == 0 && i < pr.nA) g.rowMax[pr.bestRow + i] = v;
+                // The row's best exact cosine is within one margin of its approximation, which is therefore at
+                // least the largest approximation minus two margins; 1e-5 more pays for the rounding of the
+                // accumulators of the second sweep (they start at the bar instead of zero).  A row without a
+                // finite maximum (NaNs only) gets the pair's bound.  Stored negated, as the second sweep uses it.
+                const float bar = (v == v) ? fmaxf(v - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m) : pr.thr_m;
+                if ((lane & 15) == 0 && i < pr.nA) g.rowMax[pr.bestRow + i] = -bar;
             }
         return;
     }
+    if constexpr (MODE == 2) {
+        // the wave's list, cut back into its S slices; the slices left over when S does not divide stay empty (an
+        // earlier pass that cut the columns into parts may have left counts there)
+        const int have = min(wq.n, wq.cap);
+        for (int k = lane; k < S; k += 64)
+            g.candCount[pr.chunkLocal * g.maxQueues + queueId * S + k] = max(0, min(sliceCap, have - k * sliceCap));
+        if (rowBlock == 0 && wave == 0)
+            for (int k = nQ0 * S + lane; k < nQueues; k += 64) g.candCount[pr.chunkLocal * g.maxQueues + k] = 0;
+    }
     if (lane == 0) {
-        g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
+        if constexpr (MODE != 2) g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
         if (wq.n > wq.cap) {
             // (the filtered passes rank cells by cosine, which is not the L2 order when norms differ: an L2 pair
             // whose fp16 strict list overflows is scored cell by cell)
@@ -1920,7 +1943,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 // take the filtered pass below.
                 g.gateMode = 1;
                 for (int phase = 0; phase < 2; phase++)
-                    for (int o = 0; o < 2; o++) {
+                    for (int o = 0; o < (phase == 0 ? 2 : 1); o++) { // bars of both images first; then one sweep against both
                         g.orient = o;
                         g.work = workList[o];
                         g.nWork = chunkWorkCount[o][ci];

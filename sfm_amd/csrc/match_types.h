@@ -43,7 +43,7 @@ struct MatchArgs {
     int nWork;            // entries of the work list (passes that walk it)
     int orient;           // filtered passes: 0 = image A's rows stay in registers, 1 = image B's
     int gateMode;         // 0 = every pair; 1 = only pairs whose pixel gate excludes nothing; 2 = only the others
-    float *rowMax;        // [rows of the chunk, as best]: largest approximate cosine of each row (two-phase filtered passes)
+    float *rowMax;        // [rows of the chunk, as best]: minus each row's bar, from its largest approximate cosine (two-phase filtered passes)
     int maxQueues;        // slices per pair (row blocks * waves * column parts), upper bound over the batch
     int colSplit;         // strict passes: column parts per row block (0 or 1 = a block walks all columns); work item y = row block | part << 24
     u64 *best;            // row keys and column keys of the chunk
