@@ -746,9 +746,10 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // candidate test.
 // MODE (fp16 strict instances only): the two-phase form of the filtered passes, for pairs whose pixel gate
 // excludes nothing.  A row's best cell is then its best over all columns, so
-//   1 = a sweep that only finds every row's largest approximate cosine (no candidates) and leaves the row's bar,
-//       max(that maximum - 2 margins, the pair's bound); it runs once with each image in the register-resident
-//       role, so that the rows of both images have bars; and
+//   1 = a sweep that only finds the largest approximate cosine of every row and of every column (no
+//       candidates) and leaves their bars, max(that maximum - 2 margins, the pair's bound): the rows' from the
+//       wave's registers, the columns' through maxima in LDS per block and step and atomic maxima in global
+//       memory per pair (match_col_bars_kernel turns those into bars); and
 //   2 = one strict sweep whose accumulators start at minus the lower of the cell's two bars (its row's, in
 //       registers; its column's, staged beside the column's descriptors): what stays positive is within reach
 //       of its row's best or of its column's best and is queued.
@@ -773,6 +774,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? SIM_BN : 1];
     __shared__ unsigned rowBound[GENERAL ? SIM_BLOCK_ROWS : 1];
     __shared__ float colBar[MODE == 2 ? 2 : 1][MODE == 2 ? SIM_BN : 1]; // minus the bars of the staged columns
+    __shared__ unsigned colMaxL[MODE == 1 ? 2 : 1][MODE == 1 ? SIM_BN : 1]; // largest approximation of each staged column over the block's rows
 
     const int2 w = g.work[workItem];
     if (w.x < 0) return;
@@ -934,6 +936,18 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) rowVal[t][q] = fmaxf(fmaxf(rowVal[t][q], acc.a[0][t][q]), acc.a[1][t][q]);
+            // The columns' maxima, for the bars of the other image: over the lane's 16 rows here, over the block's
+            // 256 in LDS, over the pair's rows in global memory (below).  From zero up: a cell at or below zero is
+            // nobody's best (match.cpp:38,68), and floats from zero up order like their bit patterns.
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++) {
+                float cm = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) cm = fmaxf(fmaxf(cm, acc.a[ct][t][q]), acc.a[ct][t][q + 1]);
+                atomicMax(&colMaxL[buf][(colBase & (SIM_BN - 1)) + ct * 16 + (lane & 15)], __float_as_uint(cm));
+            }
         } else
             sim_epilogue<AccT, DOT, GENERAL, MODE == 2>(g, pr, acc, rowBase, colBase, lane,
                                              typename AccT::VT(I8 ? thr_i : (MODE == 2 ? 0.0f : thr_m)), wq, localLo,
@@ -968,7 +982,20 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             test(acc, c * SIM_BN + 32, buf);
         }
         if (!(ABL & 1)) __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
+        if constexpr (MODE == 1) {
+            // One wave hands the step's column maxima on and clears them for the step after the next (which
+            // writes them after the next barrier).
+            if (wave == (c & 3)) {
+                const unsigned v = colMaxL[buf][lane];
+                colMaxL[buf][lane] = 0u;
+                const int j = c * SIM_BN + lane;
+                if (v != 0u && j < pr.nB) atomicMax(reinterpret_cast<unsigned *>(g.rowMax) + pr.bestCol + j, v);
+            }
+        }
     };
+    if constexpr (MODE == 1) {
+        if (tid < 2 * SIM_BN) colMaxL[tid / SIM_BN][tid % SIM_BN] = 0u;
+    }
     if (chunk0 < nChunks) dma_issue(chunk0, 0);
     __syncthreads();
     for (int c = chunk0; c < nChunks; c += 2) {
@@ -1012,6 +1039,20 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             g.pairOvf[pr.chunkLocal] = flag;
             atomicAdd(&g.flagCount[flag], 1); // "some pair carries this flag", for the passes that walk the list
         }
+    }
+}
+
+// Between the two-phase sweeps: the largest approximations of a pair's columns (bit patterns, from zero up) become
+// minus the columns' bars, the form the rows' are stored in.
+__global__ __launch_bounds__(256) void match_col_bars_kernel(const MatchArgs g)
+{
+    const int p = blockIdx.y;
+    if (g.pairOvf[p] != 1) return;
+    const PairRec pr = g.pairs[p];
+    if (!pr.gateOff) return;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < pr.nB; j += gridDim.x * 256) {
+        const float mx = __uint_as_float(reinterpret_cast<const unsigned *>(g.rowMax)[pr.bestCol + j]);
+        g.rowMax[pr.bestCol + j] = -fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
     }
 }
 
@@ -1942,13 +1983,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 // against that bar, each with both images in the register-resident role.  The other flagged pairs
                 // take the filtered pass below.
                 g.gateMode = 1;
-                for (int phase = 0; phase < 2; phase++)
-                    for (int o = 0; o < (phase == 0 ? 2 : 1); o++) { // bars of both images first; then one sweep against both
-                        g.orient = o;
-                        g.work = workList[o];
-                        g.nWork = chunkWorkCount[o][ci];
-                        hipLaunchKernelGGL(phase == 0 ? kSimRowMax : kSimBar, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
-                    }
+                g.orient = 0;
+                g.work = workList[0];
+                g.nWork = chunkWorkCount[0][ci];
+                SFM_HIP(ctx, hipMemsetAsync(g.rowMax, 0, (size_t)bestLen * sizeof(float), st)); // column maxima start at zero
+                hipLaunchKernelGGL(kSimRowMax, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
+                hipLaunchKernelGGL(match_col_bars_kernel, dim3(8, np), dim3(256), 0, st, g);
+                hipLaunchKernelGGL(kSimBar, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
                 g.gateMode = 2;
             }
             for (int o = 0; o < 2; o++) {
