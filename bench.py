@@ -366,7 +366,7 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
                     "fp16 bound instead of int8: half the MFMA rate, a margin of 1.5e-3 instead of 2-4e-2"))
     loose = np.ascontiguousarray(pair_list[:min(len(pair_list), 1024)])
     rows.append(row("the headline's images", imgset, loose, 0.5, "int8",
-                    "the reference's default threshold: nearly every cell passes, lists overflow, both filtered sweeps run"))
+                    "the reference's default threshold: nearly every cell passes, the strict lists overflow, one sweep finds the maxima of rows and columns and one collects the cells within reach of them"))
     n_img = 40
     pl = synth.exhaustive_pairs(n_img)
     d, p, c = synth.image_set(n_img, n, seed=2027, kind="gauss")

@@ -91,8 +91,8 @@ const char *sfm_version(void);
  * passes start, default; 0 = everything on one stream; results are identical;
  * either way the call's work is ordered before whatever follows it on the
  * context), "match_two_phase" (1 = pairs whose candidate lists overflow and whose
- * pixel gate excludes nothing are redone with two cheap sweeps per
- * orientation, row maxima first and a strict sweep against them second,
+ * pixel gate excludes nothing are redone with two cheap sweeps, the maxima
+ * of rows and columns first and a strict sweep against them second,
  * default; 0 = they take the filtered sweep with running row bounds like the
  * pairs with an effective gate; results are identical),
  * "cand_observe" (1 = a batch call of several chunks runs a first
