@@ -1101,7 +1101,7 @@ void sfm_launch_sim_signs(const MatchArgs &g, int blocks, hipStream_t st)
 
 static void (*const kSimGeneral)(const MatchArgs) = match_sim_walk_kernel<2, false, false, true, 0>;
 static void (*const kSimRowMax)(const MatchArgs) = match_sim_walk_kernel<3, false, false, false, 0, 1>;
-static void (*const kSimBar)(const MatchArgs) = match_sim_walk_kernel<3, false, false, false, 0, 2>;
+static void (*const kSimBar)(const MatchArgs) = match_sim_walk_kernel<2, false, false, false, 0, 2>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
