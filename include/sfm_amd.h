@@ -95,6 +95,10 @@ const char *sfm_version(void);
  * of rows and columns first and a strict sweep against them second,
  * default; 0 = they take the filtered sweep with running row bounds like the
  * pairs with an effective gate; results are identical),
+ * "match_flood_probe" (1 = a pair whose lists overflowed under the int8 bound
+ * is sampled, 64 x 256 cells, under the fp16 bound, and goes straight to the
+ * filtered passes when that bound would overflow them as well, default; 0 =
+ * it always tries the fp16 strict pass first; results are identical),
  * "cand_observe" (1 = a batch call of several chunks runs a first
  * chunk of at most 128 pairs with "cand_capacity" slots per pair, looks at how
  * far the lists filled and sizes the lists of the other chunks from that,

@@ -116,6 +116,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->span_used[0] = ctx->span_used[1] = 0;
     } else if (!strcmp(key, "match_two_phase")) {
         ctx->match_two_phase = value != 0;
+    } else if (!strcmp(key, "match_flood_probe")) {
+        ctx->match_flood_probe = value != 0;
     } else if (!strcmp(key, "cand_observe")) {
         ctx->cand_observe = value != 0;
     } else if (!strcmp(key, "match_overlap")) {

@@ -1056,6 +1056,53 @@ __global__ __launch_bounds__(256) void match_col_bars_kernel(const MatchArgs g)
     }
 }
 
+// After the int8 strict pass: a pair whose int8 lists overflowed goes to the fp16 strict pass next, which is wasted
+// on it if those lists overflow too (a loose threshold: the reference's default admits most cells).  This looks
+// at 64 rows x 256 columns spread over the pair; when the fp16 bound admits cells at a rate that would fill a
+// wave's slice four times over, the pair is handed straight to the filtered passes.  A guess either way costs time
+// only: every path gives the same lists.  (Cosine only: an L2 pair that overflows is scored cell by cell, far
+// too dear for a guess.)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void match_flood_probe_kernel(const MatchArgs g)
+{
+    __shared__ int total;
+    const int p = blockIdx.x;
+    if (g.pairOvf[p] != 3) return;
+    const PairRec pr = g.pairs[p];
+    if (pr.nA < 64 || pr.nB < 256 || !(pr.thr_m > -INFINITY)) return; // (small pairs: the attempt is cheap)
+    const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    const int i = (int)(((int64_t)r * pr.nA) >> 6);
+    const half2v *a = reinterpret_cast<const half2v *>(g.desc16 + (size_t)(pr.rowA16 + i) * KDIM);
+    half2v ar[KDIM / 2];
+#pragma unroll
+    for (int q = 0; q < KDIM / 2; q++) ar[q] = a[q];
+    int hits = 0;
+    for (int k = 0; k < 64; k++) {
+        const int j = (int)(((int64_t)(cg * 64 + k) * pr.nB) >> 8);
+        const half2v *b = reinterpret_cast<const half2v *>(g.desc16 + (size_t)(pr.rowB16 + j) * KDIM);
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < KDIM / 2; q += 2) {
+            s0 = __builtin_amdgcn_fdot2(ar[q], b[q], s0, false);
+            s1 = __builtin_amdgcn_fdot2(ar[q + 1], b[q + 1], s1, false);
+        }
+        hits += (s0 + s1 > pr.thr_m) ? 1 : 0;
+    }
+    atomicAdd(&total, hits);
+    __syncthreads();
+    if (tid == 0) {
+        const int nQ0 = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock, parts = max(g.colSplit, 1);
+        const double sliceCap = (double)(g.candCap / (nQ0 * parts));
+        const double expect = (double)total / (64.0 * 256.0) * 64.0 * ((double)pr.nB / parts); // of one wave's slice
+        if (expect >= 4.0 * sliceCap) {
+            g.pairOvf[p] = 1;
+            atomicAdd(&g.flagCount[1], 1);
+        }
+    }
+}
+
 // One work item per block: the pass every pair takes.
 template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
 __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
@@ -1971,6 +2018,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 if (rc != SFM_OK) return rc;
             }
             if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
+                if (ctx->match_flood_probe && metric == SFM_METRIC_COSINE)
+                    hipLaunchKernelGGL(match_flood_probe_kernel, dim3(np), dim3(256), 0, st, g);
                 g.onlyFlagged = 3;
                 g.nWork = nblk;
                 hipLaunchKernelGGL(variant.strict16, dim3(std::min(nblk, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);

@@ -533,3 +533,27 @@ def test_byte_tables_through_the_pair_call(ctx, oracle):
         assert np.array_equal(flt, exp) and np.array_equal(f1, e1) and np.array_equal(f2, e2), (nA, nB, dim, thr)
     with pytest.raises(capi.SfmError):
         ctx.match_pair(np.zeros((4, 200), np.uint8), np.zeros((4, 2)), np.zeros((4, 200), np.uint8), np.zeros((4, 2)))
+
+
+def test_flood_probe_changes_nothing(ctx, oracle):
+    """Pairs the int8 bound floods are probed (64 x 256 cells under the fp16 bound) and, when that bound would flood
+    as well, handed straight to the filtered passes instead of trying the fp16 strict pass first.  With the probe on
+    or off the lists are the restatement's: at a loose threshold (the probe skips the attempt), at a tight one on
+    descriptors whose unrelated cosines sit inside the int8 margin only (it must not), and on images too small to probe."""
+    rng = np.random.default_rng(11)
+    n = 1100
+    d, p, _ = synth.image_set(3, n, shared_frac=0.4, seed=77)
+    base = synth.sift_like(rng, 1)[0]
+    hard = np.clip(base[None, :] * 0.9 + synth.sift_like(rng, 2 * n) * 0.42, 0, 255).astype(np.float32)
+    hard[n:n + 300] = hard[:300]
+    cases = [(d[:n], p[:n], d[n:2 * n], p[n:2 * n], 0.5), (d[:n], p[:n], d[2 * n:], p[2 * n:], 0.2),
+             (hard[:n], p[:n], hard[n:], p[n:2 * n], 0.95), (d[:60], p[:60], d[n:n + 200], p[n:n + 200], 0.3)]
+    for dA, pA, dB, pB, thr in cases:
+        exp, e1, e2 = oracle.match(dA, pA, dB, pB, threshold=thr, max_dist_sq=1e8)
+        for probe in (1, 0):
+            ctx.set_option("match_flood_probe", probe)
+            try:
+                got, g1, g2 = ctx.match_pair(dA, pA, dB, pB, threshold=thr, max_dist_sq=1e8, return_best=True)
+            finally:
+                ctx.set_option("match_flood_probe", 1)
+            assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2), (thr, probe)
