@@ -784,9 +784,9 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     // Small launches of the strict passes cut the columns into parts, one block per (row block, part): a pair
     // of 8192 x 8192 is 32 row blocks, far too few for 256 CUs.  The filtered passes need all columns of a row
     // in one wave, in order: they take the items of part 0 and walk every column.
-    const int colParts = TWOSIDED ? 1 : max(g.colSplit, 1);
+    const int colParts = GENERAL ? 1 : max(g.colSplit, 1); // (the two-phase sweeps take column parts like the strict passes)
     const int colPart = w.y >> 24, rowBlock = w.y & 0xFFFFFF;
-    if (TWOSIDED && colPart != 0) return;
+    if (GENERAL && colPart != 0) return;
     // slices of the pair's candidate list: one per wave (and column part) of a strict pass, or one per wave
     // of both orientations of the general pass
     const int nQ0 = ((pr.nA + SIM_BLOCK_ROWS - 1) / SIM_BLOCK_ROWS) * SIM_WAVES;
@@ -913,8 +913,11 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             }
     };
     // this wave's slice of the pair's candidate list
-    const int nQueues = TWOSIDED ? nQ0 + nQ1 : nQ0 * colParts;
-    const int queueId = ((TWOSIDED && g.orient) ? nQ0 : colPart * nQ0) + rowBlock * SIM_WAVES + wave;
+    // (MODE 2: as many slices as the filtered passes would have, nQ0 + nQ1, shared out evenly among this sweep's
+    // nQ0 * colParts waves, S >= 1 consecutive ones each: pair_queues() counts the same way)
+    const int S = MODE == 2 ? max(1, (nQ0 + nQ1) / (nQ0 * colParts)) : 1;
+    const int nQueues = MODE == 2 ? nQ0 * colParts * S : (GENERAL ? nQ0 + nQ1 : nQ0 * colParts);
+    const int queueId = ((GENERAL && g.orient) ? nQ0 : colPart * nQ0) + rowBlock * SIM_WAVES + wave;
     float localLo[GENERAL ? AccT::NV : 1];
 #pragma unroll
     for (int k = 0; k < (GENERAL ? AccT::NV : 1); k++) localLo[k] = -INFINITY;
@@ -923,7 +926,6 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     // (The sweep against the bars of both images runs in one orientation only: its waves share out all slices of
     // the pair, S consecutive ones each, and fill them as one list.)
     const int sliceCap = g.candCap / nQueues;
-    const int S = MODE == 2 ? nQueues / nQ0 : 1;
     wq.cap = sliceCap * S;
     wq.base = g.cand + (size_t)pr.chunkLocal * g.candCap + (size_t)queueId * S * sliceCap;
     wq.n = 0;
@@ -1012,23 +1014,17 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 #pragma unroll
                 for (int d = 1; d < 16; d <<= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
                 const int i = rowBase + 16 * t + 4 * (lane >> 4) + q;
-                // The row's best exact cosine is within one margin of its approximation, which is therefore at
-                // least the largest approximation minus two margins; 1e-5 more pays for the rounding of the
-                // accumulators of the second sweep (they start at the bar instead of zero).  A row without a
-                // finite maximum (NaNs only) gets the pair's bound.  Stored negated, as the second sweep uses it.
-                const float bar = (v == v) ? fmaxf(v - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m) : pr.thr_m;
-                if ((lane & 15) == 0 && i < pr.nA) g.rowMax[pr.bestRow + i] = -bar;
+                // (from zero up, like the columns': the blocks of the row's other column parts add theirs)
+                if ((lane & 15) == 0 && i < pr.nA)
+                    atomicMax(reinterpret_cast<unsigned *>(g.rowMax) + pr.bestRow + i, __float_as_uint(fmaxf(v, 0.0f)));
             }
         return;
     }
     if constexpr (MODE == 2) {
-        // the wave's list, cut back into its S slices; the slices left over when S does not divide stay empty (an
-        // earlier pass that cut the columns into parts may have left counts there)
+        // the wave's list, cut back into its S slices
         const int have = min(wq.n, wq.cap);
         for (int k = lane; k < S; k += 64)
             g.candCount[pr.chunkLocal * g.maxQueues + queueId * S + k] = max(0, min(sliceCap, have - k * sliceCap));
-        if (rowBlock == 0 && wave == 0)
-            for (int k = nQ0 * S + lane; k < nQueues; k += 64) g.candCount[pr.chunkLocal * g.maxQueues + k] = 0;
     }
     if (lane == 0) {
         if constexpr (MODE != 2) g.candCount[pr.chunkLocal * g.maxQueues + queueId] = min(wq.n, wq.cap);
@@ -1042,17 +1038,20 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     }
 }
 
-// Between the two-phase sweeps: the largest approximations of a pair's columns (bit patterns, from zero up) become
-// minus the columns' bars, the form the rows' are stored in.
+// Between the two-phase sweeps: the largest approximations of a pair's rows and columns (bit patterns, from zero
+// up) become their bars.  A row's (column's) best exact cosine is within one margin of its approximation, which is
+// therefore at least the largest approximation minus two margins; 1e-5 more pays for the rounding of the second
+// sweep's accumulators (they start at the bar instead of zero).  Stored negated, as the second sweep uses them.
 __global__ __launch_bounds__(256) void match_col_bars_kernel(const MatchArgs g)
 {
     const int p = blockIdx.y;
     if (g.pairOvf[p] != 1) return;
     const PairRec pr = g.pairs[p];
     if (!pr.gateOff) return;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < pr.nB; j += gridDim.x * 256) {
-        const float mx = __uint_as_float(reinterpret_cast<const unsigned *>(g.rowMax)[pr.bestCol + j]);
-        g.rowMax[pr.bestCol + j] = -fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < pr.nA + pr.nB; k += gridDim.x * 256) {
+        const int64_t at = k < pr.nA ? pr.bestRow + k : pr.bestCol + (k - pr.nA);
+        const float mx = __uint_as_float(reinterpret_cast<const unsigned *>(g.rowMax)[at]);
+        g.rowMax[at] = -fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
     }
 }
 
@@ -1161,7 +1160,10 @@ __device__ __forceinline__ int pair_queues(const MatchArgs &g, const PairRec &pr
 {
     const int nQ0 = ((pr.nA + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
     const int nQ1 = ((pr.nB + g.blockRows - 1) / g.blockRows) * g.wavesPerBlock;
-    return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0 * max(g.colSplit, 1);
+    const int parts = max(g.colSplit, 1);
+    if (g.pairOvf[p] == 1 && g.rowMax && pr.gateOff) // the sweep against the bars laid them out (sim_block, MODE 2)
+        return nQ0 * parts * max(1, (nQ0 + nQ1) / (nQ0 * parts));
+    return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0 * parts;
 }
 
 // One wave per candidate slice, four slices per block.  RATIO: the second sweep of the ratio mode;
