@@ -1042,7 +1042,9 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 // up) become their bars.  A row's (column's) best exact cosine is within one margin of its approximation, which is
 // therefore at least the largest approximation minus two margins; 1e-5 more pays for the rounding of the second
 // sweep's accumulators (they start at the bar instead of zero).  Stored negated, as the second sweep uses them.
-__global__ __launch_bounds__(256) void match_col_bars_kernel(const MatchArgs g)
+// CLEAR: before the first sweep, the maxima of the pairs that will take it start at zero (only theirs: a chunk
+// without such pairs, the usual case, touches nothing).
+template <bool CLEAR> __global__ __launch_bounds__(256) void match_col_bars_kernel(const MatchArgs g)
 {
     const int p = blockIdx.y;
     if (g.pairOvf[p] != 1) return;
@@ -1050,8 +1052,12 @@ __global__ __launch_bounds__(256) void match_col_bars_kernel(const MatchArgs g)
     if (!pr.gateOff) return;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < pr.nA + pr.nB; k += gridDim.x * 256) {
         const int64_t at = k < pr.nA ? pr.bestRow + k : pr.bestCol + (k - pr.nA);
-        const float mx = __uint_as_float(reinterpret_cast<const unsigned *>(g.rowMax)[at]);
-        g.rowMax[at] = -fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
+        if (CLEAR) {
+            reinterpret_cast<unsigned *>(g.rowMax)[at] = 0u;
+        } else {
+            const float mx = __uint_as_float(reinterpret_cast<const unsigned *>(g.rowMax)[at]);
+            g.rowMax[at] = -fmaxf(mx - 2.0f * SIM_MARGIN - 1e-5f, pr.thr_m);
+        }
     }
 }
 
@@ -2037,9 +2043,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 g.orient = 0;
                 g.work = workList[0];
                 g.nWork = chunkWorkCount[0][ci];
-                SFM_HIP(ctx, hipMemsetAsync(g.rowMax, 0, (size_t)bestLen * sizeof(float), st)); // column maxima start at zero
+                hipLaunchKernelGGL(match_col_bars_kernel<true>, dim3(8, np), dim3(256), 0, st, g);
                 hipLaunchKernelGGL(kSimRowMax, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
-                hipLaunchKernelGGL(match_col_bars_kernel, dim3(8, np), dim3(256), 0, st, g);
+                hipLaunchKernelGGL(match_col_bars_kernel<false>, dim3(8, np), dim3(256), 0, st, g);
                 hipLaunchKernelGGL(kSimBar, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
                 g.gateMode = 2;
             }
