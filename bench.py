@@ -335,16 +335,16 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     unrelated descriptors sit at cosine 0.93, inside the int8 margin of a 0.95 threshold (every pair is redone
     with the fp16 bound).  `frac` prices the strict bound kernel alone against its MFMA peak; `end_to_end_frac`
     prices the whole call (all passes) against the peak of the bound the row starts with."""
-    from sfm_amd import synth
+    from sfm_amd import capi, synth
     n = args.features
 
-    def row(label, s, pl, thr, variant, note):
+    def row(label, s, pl, thr, variant, note, metric=0):
         sv, dtype, peak = BOUNDS[variant]
         ctx.set_option("sim_variant", sv)
-        res = s.match(pl, threshold=thr, max_dist_sq=1e8)
+        res = s.match(pl, threshold=thr, max_dist_sq=1e8, metric=metric)
         ctx.synchronize()
         t0 = time.perf_counter()
-        res = s.match(pl, threshold=thr, max_dist_sq=1e8, result=res)
+        res = s.match(pl, threshold=thr, max_dist_sq=1e8, result=res, metric=metric)
         ctx.synchronize()
         dt = time.perf_counter() - t0
         ms, launches = ctx.last_kernel_ms(0)
@@ -358,6 +358,11 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
                "pairs_scored_cell_by_cell": cells, "pairs_through_filtered_passes": filtered,
                "pairs_redone_with_fp16_bound": redone, "note": note}
         res.close()
+        return out
+
+    def row_metric(label, s, pl, thr, variant, metric, note):
+        out = row(label, s, pl, thr, variant, note, metric=metric)
+        out["metric"] = "dot" if metric == capi.METRIC_DOT else "cosine"
         return out
 
     rows = []
@@ -375,6 +380,15 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
                     s, pl, args.threshold, "int8", "general floats: exact pass reads the fp32 table"))
     rows.append(row(f"{n_img} images x {n} Gaussian float descriptors", s, pl, 0.5, "int8",
                     "unrelated Gaussian descriptors have cosine ~ N(0, 1/128): 0.5 is still selective"))
+    s.close()
+    # the reference's other metric on descriptors of unit norm, where it equals the cosine up to rounding
+    d, p, c = synth.image_set(24, n, seed=2026)
+    unit = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    s = ctx.imageset(c, unit, p)
+    pl24 = synth.exhaustive_pairs(24)
+    rows.append(row_metric("24 of the headline's images, rows scaled to unit norm, dotProduct (match.hpp:18-27)", s, pl24, args.threshold,
+                           "int8", capi.METRIC_DOT, "a.b > T implies a cosine above T / (maxA maxB): strict passes under that bound, "
+                                                    "the exact pass scores the dot product"))
     s.close()
     rng = np.random.default_rng(7)
     base = synth.sift_like(rng, 1)[0]

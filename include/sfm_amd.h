@@ -99,6 +99,11 @@ const char *sfm_version(void);
  * is sampled, 64 x 256 cells, under the fp16 bound, and goes straight to the
  * filtered passes when that bound would overflow them as well, default; 0 =
  * it always tries the fp16 strict pass first; results are identical),
+ * "match_dot_strict" (1 = with the dot metric a pair first takes the strict
+ * passes under the cosine bound threshold / (largest norm of A x largest
+ * norm of B), which is tight for descriptors of unit norm, default; 0 = the
+ * bound is scaled by the two norms cell by cell for every pair; results are
+ * identical),
  * "cand_observe" (1 = a batch call of several chunks runs a first
  * chunk of at most 128 pairs with "cand_capacity" slots per pair, looks at how
  * far the lists filled and sizes the lists of the other chunks from that,

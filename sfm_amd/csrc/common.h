@@ -25,6 +25,7 @@ struct sfm_ctx {
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
     int match_two_phase = 1;         // 0: flagged pairs always take the filtered pass with running row bounds
     int match_flood_probe = 1;       // 0: pairs the int8 bound flooded always try the fp16 strict pass before the filtered ones
+    int match_dot_strict = 1;        // 0: the dot metric scales the bound by the norms cell by cell for every pair
     int cand_observe = 1;            // calls of several chunks size the candidate lists of later chunks from the first one
     int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test

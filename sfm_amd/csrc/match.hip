@@ -303,6 +303,7 @@ struct BoundArgs {
     float threshold;
     float ratio;
     float maxDistSq;
+    int dotStrict; // dot metric: make a cosine bound for the strict passes (see below)
 };
 __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ pairs, int nPairs, const BoundArgs b)
 {
@@ -330,6 +331,18 @@ __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ 
         thrp = open ? 0.0f : (float)c;
         wild = wild || open;
     }
+    const bool dotStrict = b.metric == SFM_METRIC_DOT && b.dotStrict != 0;
+    if (dotStrict && thrp > 0.0f) {
+        // a.b > T > 0  =>  cos > T / (|a| |b|) >= T / (maxA maxB): the strict passes bound the cosine, the exact
+        // pass scores the dot product itself.  (The reference's fp32 dot product is within 8e-6 |a| |b| of the
+        // exact one, which the margins of both bounds cover.)  No descriptor inside the safe range: no bound.
+        const int *range = b.stats + 2 * (size_t)b.nImages;
+        const double maxA = (double)__int_as_float(range[2 * ia + 1]), maxB = (double)__int_as_float(range[2 * ib + 1]);
+        const double c = (double)thrp / (maxA * maxB) * (1.0 - 1e-6) - 1e-6;
+        const bool open = !(maxA * maxB > 0.0) || !(c == c);
+        thrp = open ? 0.0f : (float)(c < 4.0 ? c : 4.0); // (beyond 1 nothing passes, as it must not)
+        wild = wild || open;
+    }
     // Ratio mode: a row whose best has similarity s1 > threshold is undone by any column at or
     // above 1 - (1 - s1) / ratio^2, which is more than 1 - (1 - threshold) / ratio^2: the bound
     // pass collects down to there, and the exact pass still applies the threshold itself.
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ 
     float thr_m;
     if (wild)
         thr_m = -INFINITY;
-    else if (b.metric == SFM_METRIC_DOT)
+    else if (b.metric == SFM_METRIC_DOT && !dotStrict)
         thr_m = (thrp == 0.0f) ? -SIM_MARGIN : 0.0f; // a positive bound on the dot product is tested per cell
     else
         thr_m = (threshold != threshold) ? threshold : thrp - SIM_MARGIN; // (L2: thrp may be negative here)
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ 
     int thr_i;
     if (threshold != threshold)
         thr_i = INT_MAX;
-    else if (wild || b.metric == SFM_METRIC_DOT || !(t > -1e9))
+    else if (wild || (b.metric == SFM_METRIC_DOT && !dotStrict) || !(t > -1e9))
         thr_i = -(1 << 30);
     else
         thr_i = (int)floor(t < 2.0e9 ? t : 2.0e9);
@@ -1169,7 +1182,7 @@ __device__ __forceinline__ int pair_queues(const MatchArgs &g, const PairRec &pr
     const int parts = max(g.colSplit, 1);
     if (g.pairOvf[p] == 1 && g.rowMax && pr.gateOff) // the sweep against the bars laid them out (sim_block, MODE 2)
         return nQ0 * parts * max(1, (nQ0 + nQ1) / (nQ0 * parts));
-    return (g.metric == SFM_METRIC_DOT || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0 * parts;
+    return ((g.metric == SFM_METRIC_DOT && !g.dotStrict) || g.pairOvf[p] == 1) ? nQ0 + nQ1 : nQ0 * parts;
 }
 
 // One wave per candidate slice, four slices per block.  RATIO: the second sweep of the ratio mode;
@@ -1875,6 +1888,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killSet * sets));
     // two-phase filtered passes (cosine): one float per row of a chunk
     const bool twoPhase = ctx->match_two_phase && metric == SFM_METRIC_COSINE && candCapMax > 0;
+    // The dot metric (match.hpp:18-27) takes the strict passes first as well: a.b > T > 0 implies a cosine above
+    // T / (maxA maxB) (pair_bounds_kernel), and the exact pass scores the dot product; pairs whose lists overflow go
+    // on to the pass that tests the dot product cell by cell against the norms.  (Not with the ratio test, whose
+    // bound is made for the cosine.)
+    const bool dotStrict = metric == SFM_METRIC_DOT && ctx->match_dot_strict && ratio == 0.0f && candCapMax > 0;
     const size_t rowMaxSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(float)), 256);
     if (twoPhase) SFM_HIP(ctx, res->rowMax.reserve(rowMaxSet * sets));
     // The single-pair entry point fetches everything with one copy: its count, the per-row and per-column bests
@@ -1910,6 +1928,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.pts = set->pts.as<double2>();
     g.maxQueues = maxQueues;
     g.colSplit = colSplit;
+    g.dotStrict = dotStrict ? 1 : 0;
     g.blockRows = BLOCK_ROWS;
     g.wavesPerBlock = wavesPerBlock;
     g.stats = res->stats.as<u64>();
@@ -1953,7 +1972,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             SFM_HIP(ctx, hipMemcpyAsync(res->work.as<int2>() + w0, work + w0, (size_t)wn * sizeof(int2), hipMemcpyHostToDevice, up));
         const int nImg = set->n_images ? set->n_images : 1;
         const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, set->imageStats.as<unsigned>() + 5 * (size_t)nImg,
-                             nImg, set->dim, metric, threshold, ratio, maxDistSq};
+                             nImg, set->dim, metric, threshold, ratio, maxDistSq, dotStrict ? 1 : 0};
         hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, up, res->pairRecs.as<PairRec>() + c0, np, b);
         if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[7 + (int)(ci % (size_t)sets)], up));
         return SFM_OK;
@@ -2004,8 +2023,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
         if (nblk > 0) {
             const bool cosine = metric != SFM_METRIC_DOT; // the L2 mode runs the cosine bound passes with its own per-pair bound
+            const bool strictFirst = cosine || dotStrict;  // (the dot metric too, under a cosine bound from the images' largest norms)
             bool forked = false;
-            if (cosine) {
+            if (strictFirst) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
                 hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
@@ -2025,7 +2045,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 const int rc = upload(ci + 1);
                 if (rc != SFM_OK) return rc;
             }
-            if (cosine && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
+            if (strictFirst && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 if (ctx->match_flood_probe && metric == SFM_METRIC_COSINE)
                     hipLaunchKernelGGL(match_flood_probe_kernel, dim3(np), dim3(256), 0, st, g);
                 g.onlyFlagged = 3;
@@ -2034,7 +2054,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             }
             // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
             // orientations.  Dot: every pair takes this path.
-            g.onlyFlagged = cosine ? 1 : 0;
+            g.onlyFlagged = strictFirst ? 1 : 0;
             if (twoPhase) {
                 // Pairs whose pixel gate excludes nothing: every row's largest approximation, then a strict sweep
                 // against that bar, each with both images in the register-resident role.  The other flagged pairs
@@ -2052,11 +2072,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             for (int o = 0; o < 2; o++) {
                 g.orient = o;
                 g.work = workList[o];
-                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
+                if (!strictFirst && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.nWork = chunkWorkCount[o][ci];
                 hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(cosine ? std::min(g.nWork, walkGrid) : g.nWork),
                                    dim3(SIM_WAVES * 64), 0, st, g);
-                if (!cosine && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
+                if (!strictFirst && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
             }
             g.gateMode = 0;
             if (probe) SFM_HIP(ctx, observe(st, np));

@@ -45,6 +45,7 @@ struct MatchArgs {
     int gateMode;         // 0 = every pair; 1 = only pairs whose pixel gate excludes nothing; 2 = only the others
     float *rowMax;        // [rows of the chunk, as best]: minus each row's bar, from its largest approximate cosine (two-phase filtered passes)
     int maxQueues;        // slices per pair (row blocks * waves * column parts), upper bound over the batch
+    int dotStrict;        // dot metric: 1 = the pairs take the strict passes first, under a cosine bound made from the images' largest norms
     int colSplit;         // strict passes: column parts per row block (0 or 1 = a block walks all columns); work item y = row block | part << 24
     u64 *best;            // row keys and column keys of the chunk
     int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many

@@ -557,3 +557,41 @@ def test_flood_probe_changes_nothing(ctx, oracle):
             finally:
                 ctx.set_option("match_flood_probe", 1)
             assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2), (thr, probe)
+
+
+@pytest.mark.parametrize("spread", [0.0, 0.2])
+def test_dot_metric_through_the_strict_passes(ctx, oracle, spread):
+    """dotProduct (match.hpp:18-27) on descriptors of unit or nearly unit norm: a.b > T implies a cosine above
+    T / (maxA maxB), so the pairs take the strict passes under that bound and the exact pass scores the dot
+    product.  Lists and bests are the restatement's with that path on or off, in a single call and in a batch,
+    also where the bound is useless (raw rows, threshold 0) and where nothing can pass (threshold above every
+    product of norms)."""
+    rng = np.random.default_rng(5)
+    n = 1200
+    d, p, _ = synth.image_set(3, n, shared_frac=0.5, seed=91)
+    u = d / np.linalg.norm(d, axis=1, keepdims=True)
+    u = (u * (1.0 + spread * rng.uniform(-1, 1, size=(len(u), 1)))).astype(np.float32)
+    for thr in (0.9, 0.6, 0.0, 2.5):
+        exp, e1, e2 = oracle.match(u[:n], p[:n], u[n:2 * n], p[n:2 * n], threshold=thr, max_dist_sq=1e8, metric=1)
+        for strict in (1, 0):
+            ctx.set_option("match_dot_strict", strict)
+            try:
+                got, g1, g2 = ctx.match_pair(u[:n], p[:n], u[n:2 * n], p[n:2 * n], threshold=thr, max_dist_sq=1e8, metric=1,
+                                             return_best=True)
+            finally:
+                ctx.set_option("match_dot_strict", 1)
+            assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2), (thr, strict)
+        if thr == 0.9:
+            assert len(exp) > 100
+    counts = np.array([n, n, n], np.int32)
+    s = ctx.imageset(counts, u, p)
+    pl = np.array([[0, 1], [0, 2], [1, 2], [2, 2]], np.int32)
+    res = s.match(pl, threshold=0.9, max_dist_sq=1e8, metric=1)
+    off, pairs = res.offsets(), res.pairs()
+    cand, cells, filtered, redone = res.stats_ex()
+    assert cells == 0 and filtered == 0, "unit rows at a tight threshold need neither fallback"
+    for k, (a, b) in enumerate(pl):
+        exp, _, _ = oracle.match(u[a * n:(a + 1) * n], p[a * n:(a + 1) * n], u[b * n:(b + 1) * n], p[b * n:(b + 1) * n],
+                                 threshold=0.9, max_dist_sq=1e8, metric=1)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp), k
+    s.close()
