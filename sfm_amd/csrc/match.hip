@@ -1773,8 +1773,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     // fill it unevenly with a few long blocks, is cut into more and shorter ones.  Every part keeps at least
     // eight steps of 64 columns, and the slices of a pair's candidate list stay within what the exact pass
     // numbers in one block (1024).
+    // The dot metric (match.hpp:18-27) takes the strict passes first as well: a.b > T > 0 implies a cosine above
+    // T / (maxA maxB) (pair_bounds_kernel), and the exact pass scores the dot product; pairs whose lists overflow go
+    // on to the pass that tests the dot product cell by cell against the norms.  (Not with the ratio test, whose
+    // bound is made for the cosine.)
+    const bool dotStrict = metric == SFM_METRIC_DOT && ctx->match_dot_strict && ratio == 0.0f && candCapMax > 0;
     int colSplit = 1;
-    if (metric != SFM_METRIC_DOT && mostBlocks > 0) {
+    if ((metric != SFM_METRIC_DOT || dotStrict) && mostBlocks > 0) {
         const int64_t want = 16 * (int64_t)ctx->n_cus; // three rounds of five blocks per CU: short blocks level the CUs out
         const int stepsB = (maxNB + SIM_BN - 1) / SIM_BN;
         const int queuesA = ((maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS) * wavesPerBlock;
@@ -1888,11 +1893,6 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killSet * sets));
     // two-phase filtered passes (cosine): one float per row of a chunk
     const bool twoPhase = ctx->match_two_phase && metric == SFM_METRIC_COSINE && candCapMax > 0;
-    // The dot metric (match.hpp:18-27) takes the strict passes first as well: a.b > T > 0 implies a cosine above
-    // T / (maxA maxB) (pair_bounds_kernel), and the exact pass scores the dot product; pairs whose lists overflow go
-    // on to the pass that tests the dot product cell by cell against the norms.  (Not with the ratio test, whose
-    // bound is made for the cosine.)
-    const bool dotStrict = metric == SFM_METRIC_DOT && ctx->match_dot_strict && ratio == 0.0f && candCapMax > 0;
     const size_t rowMaxSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(float)), 256);
     if (twoPhase) SFM_HIP(ctx, res->rowMax.reserve(rowMaxSet * sets));
     // The single-pair entry point fetches everything with one copy: its count, the per-row and per-column bests
