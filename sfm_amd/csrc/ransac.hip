@@ -56,6 +56,7 @@ struct RansacArgs {
     int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
     int mfma;     // 1: unsplit launches run the pre-test on the matrix cores (ransac_score_mfma_kernel)
     int mfKe;     // and scale the hypothesis side of num by 2^mfKe
+    double mfI[2]; // that test's 1/fx, 1/fy: the camera's for the reprojection loss, 2/(fx + fy) twice for the Sampson distance
     uint4 *mfOps; // the correspondence side of that test, made once per call (see mfma_ops_start), or NULL: the
                   // scoring kernel makes it from the fp32 records as it goes
     double maxSqErr;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
 #pragma unroll
         for (int i = 0; i < 9; i++) dst[i] = r[i];
         dst[9] = 0.0;
-        return;
+        if (!g.mfma) return; // (Sampson distance: unsplit launches run the matrix-core test, split ones the instances above)
     }
     // x1h.x1h for the scoring kernel's pre-test, or +inf for a correspondence it must not skip
     const double big = 1e6;
@@ -327,6 +328,13 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     double G = tame ? fmax(70.0 * (D * D), 1e-30) : INFINITY; // (kept clear of the denormals)
     if (g.mfma && tame) // the matrix-core test needs a wider margin; the packed test stays valid with it
         G = fmax(G, mfma_margin(g, r[9], r[4], fmax(fmax(fabs(r[0]), fabs(r[1])), 1.0) * fmax(fmax(fabs(r[2]), fabs(r[3])), 1.0)));
+    if (g.mfma && tame && g.loss == SFM_LOSS_SAMPSON) {
+        // Sampson = num^2 f^2 / (a + b), a = |(E x1h)_01|^2, b = |(E^T x2h)_01|^2 <= |x2h|^2 (E = [T]x R with |T| = 1
+        // has norm 1; the hypothesis side checks |T|): no inlier when num^2 >= c^2 (a + 1.001 |x2h|^2) / f^2.  The
+        // first term is the q form with 1/f for both focal lengths, the second a constant of the correspondence
+        // that rides with the margin (2e-5 of it more for its hi + lo rounding and its share of the accumulator's).
+        G += (c * c) * (g.mfI[0] * g.mfI[0]) * (1.001 * r[4]) * (1.0 + 2e-5);
+    }
     d[16] = (float)(G * 1.000001);
     if (kk == n - 1) // the rest of the last group is never read as a result
         for (int f = (kk & 3) + 1; f < 4; f++)
@@ -937,7 +945,7 @@ __device__ __forceinline__ double mfma_margin(const RansacArgs &g, double x1n2, 
     const double c = SKIP_FACTOR * sqrt(g.maxSqErr);
     const double se = ldexp(1.0, g.mfKe), sQ = ldexp(1.0, 2 * (10 + g.mfKe) - 4);
     const double D = (1.1e-5 + 3.7e-4 / se) * sqrt(x1n2 * x2n2) + 5.2e-7;
-    const double cfp = 1.4143 * (c * c) * (g.Ki[0] * g.Ki[0] + g.Ki[1] * g.Ki[1]);
+    const double cfp = 1.4143 * (c * c) * (g.mfI[0] * g.mfI[0] + g.mfI[1] * g.mfI[1]);
     const double epsq = (1.0e-5 * x1n2 + 1.9e-5) * cfp + 3.0e-4 * x1n2 / sQ;
     return (70.0 * (D * D) + 1.1 * epsq) * 1.00001;
 }
@@ -954,10 +962,11 @@ __device__ __forceinline__ void mfma_hyp_operands(const RansacArgs &g, const Pos
     bool sane = true;
 #pragma unroll
     for (int i = 0; i < 9; i++) sane = sane && (fabs(E[i / 3][i % 3]) <= 1.001);
+    sane = sane && ((P.T[0] * P.T[0] + P.T[1] * P.T[1]) + P.T[2] * P.T[2] <= 1.0005); // (the Sampson bound needs |E| <= 1)
     const float se = ldexpf(1.0f, g.mfKe);
     const double c = SKIP_FACTOR * sqrt(g.maxSqErr);
     const double sQ = ldexp(c * c, 2 * (10 + g.mfKe) - 4);
-    const double ix2 = g.Ki[0] * g.Ki[0], iy2 = g.Ki[1] * g.Ki[1];
+    const double ix2 = g.mfI[0] * g.mfI[0], iy2 = g.mfI[1] * g.mfI[1];
     const int ja[6] = {0, 1, 2, 0, 0, 1}, jb[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
     for (int k = 0; k < 64; k++) out[k] = (_Float16)0.0f;
@@ -1062,7 +1071,7 @@ __global__ __launch_bounds__(256) void ransac_mfma_ops_kernel(const RansacArgs g
     }
 }
 
-template <int T, bool PRE>
+template <int T, bool PRE, int LOSS = SFM_LOSS_REPROJECTION>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ransac_score_mfma_kernel(const RansacArgs g)
 {
     constexpr int ROWS_W = 16 * T, ROWS_B = 4 * ROWS_W;
@@ -1170,7 +1179,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
             load_pose(poseP + (size_t)(rowW0 + hl) * 12, Q);
             double r[9];
             make_record(g, base + k, r);
-            e = reprojection_loss(K, Q, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            if constexpr (LOSS == SFM_LOSS_SAMPSON) {
+                double E[3][3];
+                essential_from_pose(Q, E);
+                e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+            } else {
+                e = reprojection_loss(K, Q, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            }
             inl = e < thr; // RANSAC.cpp:216
         }
         qHead += take;
@@ -2106,26 +2121,33 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.inlOff = b->inlOff.as<int64_t>();
     g.inliers = b->inliers.as<int32_t>();
     for (int i = 0; i < 9; i++) g.K[i] = K[i];
+    bool sampsonTest = false;
     {
         // K column-major: K(r,c) = K[r + 3c].  The pre-test needs K = [fx 0 cx; 0 fy cy; 0 0 1] with
         // positive focal lengths: observations K*(x,y,1) are then pixels, and the epipolar line of a
         // hypothesis keeps a simple form in them (see the scoring kernel).
         const double fx = K[0], fy = K[4];
         const bool ok = pretest_applies(ctx, K, loss);
+        // (the Sampson distance has no packed test; its matrix-core test needs the same form of K)
+        sampsonTest = loss == SFM_LOSS_SAMPSON && pretest_applies(ctx, K, SFM_LOSS_REPROJECTION) && !no_alloc;
+        const bool form = ok || sampsonTest;
         g.filter = ok ? 1 : 0;
-        g.Ki[0] = ok ? 1.0 / fx : 0.0;
-        g.Ki[1] = ok ? 1.0 / fy : 0.0;
-        g.Ki[2] = ok ? 1.0 / std::min(fx, fy) : 0.0;
-        g.Ki[3] = ok ? std::max(fx, fy) * std::max(fx, fy) : 0.0;          // bound of |m|^2 from the scaled line
+        g.Ki[0] = form ? 1.0 / fx : 0.0;
+        g.Ki[1] = form ? 1.0 / fy : 0.0;
+        g.Ki[2] = form ? 1.0 / std::min(fx, fy) : 0.0;
+        g.Ki[3] = form ? std::max(fx, fy) * std::max(fx, fy) : 0.0;          // bound of |m|^2 from the scaled line
+        g.mfI[0] = sampsonTest ? 2.0 / (fx + fy) : g.Ki[0];
+        g.mfI[1] = sampsonTest ? 2.0 / (fx + fy) : g.Ki[1];
     }
     g.maxSqErr = maxSqErr;
     g.mfma = 0;
     g.mfOps = nullptr;
-    if (g.filter && ctx->ransac_mfma && maxSqErr > 0.0 && std::isfinite(maxSqErr)) {
+    g.loss = loss;
+    if ((g.filter || sampsonTest) && ctx->ransac_mfma && maxSqErr > 0.0 && std::isfinite(maxSqErr)) {
         // scale of the hypothesis side: the largest entry of the q form, 2 c^2 (1/fx^2 + 1/fy^2) 2^(P-4) with
         // P = 2 (10 + mfKe), must stay inside fp16 (2^15 here)
         const double c2 = SKIP_FACTOR * SKIP_FACTOR * maxSqErr;
-        const double cf2 = c2 * (g.Ki[0] * g.Ki[0] + g.Ki[1] * g.Ki[1]);
+        const double cf2 = c2 * (g.mfI[0] * g.mfI[0] + g.mfI[1] * g.mfI[1]);
         const int ke = (int)std::floor((18.0 - std::log2(cf2)) / 2.0 - 10.0);
         bool fits = ke >= -4; // (a threshold of hundreds of focal lengths: the packed test serves)
         for (int p = 0; p < n_pairs && fits; p++) fits = corr_offsets[p + 1] - corr_offsets[p] < (1 << 24); // queue entries
@@ -2200,7 +2222,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             else
                 score = Z > 1 ? ransac_score_kernel<SFM_LOSS_REPROJECTION, true, false>
                               : ransac_score_kernel<SFM_LOSS_REPROJECTION, false, false>;
-            if (pretest && Z == 1 && g.mfma && loss == SFM_LOSS_REPROJECTION)
+            if (Z == 1 && g.mfma && ((pretest && loss == SFM_LOSS_REPROJECTION) || sampsonTest))
             {
                 // The correspondence side of the test is made once per call (128 B per correspondence) when the
                 // table fits the budget; otherwise, and for the entry point that allocates nothing, every block
@@ -2220,6 +2242,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                 }
                 const dim3 mgrid((unsigned)(((rows + 255) / 256) * n_pairs));
                 void (*mk)(const RansacArgs) = g.mfOps ? ransac_score_mfma_kernel<4, true> : ransac_score_mfma_kernel<4, false>;
+                if (sampsonTest)
+                    mk = g.mfOps ? ransac_score_mfma_kernel<4, true, SFM_LOSS_SAMPSON> : ransac_score_mfma_kernel<4, false, SFM_LOSS_SAMPSON>;
                 hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
             }
             else

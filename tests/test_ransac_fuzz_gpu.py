@@ -33,6 +33,7 @@ def test_random_case(ctx, oracle, seed):
         S[rng.integers(H)] = S[0]  # a repeated sample row: the earlier one must win ties
     thr = float(rng.choice([1.0, 10.0, 0.05, 1e-6, 1e4]))
     adaptive = bool(rng.integers(2))
+    loss = int(rng.choice([0, 0, 1]))  # the reference's reprojection loss, or the Sampson distance (extension)
     # Every path of the scoring: no pre-test, the packed fp32 test, the test on the matrix cores with prepared
     # operands or with operands made by the blocks (unsplit launches only), split over correspondences or not.
     ctx.set_option("ransac_filter", int(rng.integers(2)))
@@ -40,13 +41,13 @@ def test_random_case(ctx, oracle, seed):
     ctx.set_option("ransac_mfma", int(rng.integers(2)))
     ctx.set_option("ransac_mfma_ops_gib", int(rng.choice([0, 64])))
     try:
-        got = ctx.ransac_pair(x, y, K, S, max_sq_err=thr, success_prob=0.999, adaptive=adaptive)
+        got = ctx.ransac_pair(x, y, K, S, max_sq_err=thr, success_prob=0.999, adaptive=adaptive, loss=loss)
     finally:
         ctx.set_option("ransac_filter", 1)
         ctx.set_option("ransac_split", 1)
         ctx.set_option("ransac_mfma", 1)
         ctx.set_option("ransac_mfma_ops_gib", 64)
-    exp = oracle.ransac(x, y, K, S, max_sq_err=thr, success_prob=0.999, adaptive=adaptive)
+    exp = oracle.ransac(x, y, K, S, max_sq_err=thr, success_prob=0.999, adaptive=adaptive, loss_kind=loss)
     assert np.array_equal(got["counts"], exp["counts"]), "per-row inlier counts differ"
     assert np.array_equal(got["toterr"].view(np.uint64), exp["toterr"].view(np.uint64)), "per-row error sums differ"
     assert got["best_h"] == exp["best_h"] and got["iterations"] == exp["iterations"]
@@ -67,6 +68,7 @@ def test_random_batch(ctx, oracle, seed):
                       [0.0, 0.0, 1.0]])
     thr = float(rng.choice([1.0, 10.0, 0.05, 1e-4, 1e3]))
     adaptive = bool(rng.integers(2))
+    loss = int(rng.choice([0, 0, 1]))
     xs, ys, Ss, off = [], [], [], [0]
     for k in range(P):
         n = int(rng.choice([0, 5, 8, 15, 16, 17, 63, 64, 65, 500, 1023, 2500, 6000], p=[.03, .03, .05, .05, .05, .05, .05, .05, .05, .2, .15, .14, .1]))
@@ -84,7 +86,7 @@ def test_random_batch(ctx, oracle, seed):
     ctx.set_option("ransac_mfma", int(rng.integers(2)))
     ctx.set_option("ransac_mfma_ops_gib", int(rng.choice([0, 64])))
     try:
-        b = ctx.ransac_batch(np.array(off), x, y, K, S, H, max_sq_err=thr, success_prob=0.999, adaptive=adaptive)
+        b = ctx.ransac_batch(np.array(off), x, y, K, S, H, max_sq_err=thr, success_prob=0.999, adaptive=adaptive, loss=loss)
         best = b.best()
         ioff, inl = b.inliers()
         b.close()
@@ -96,7 +98,8 @@ def test_random_batch(ctx, oracle, seed):
         n = off[k + 1] - off[k]
         if n < 8:
             continue
-        e = oracle.ransac(x[off[k]:off[k + 1]], y[off[k]:off[k + 1]], K, S[k], max_sq_err=thr, success_prob=0.999, adaptive=adaptive)
+        e = oracle.ransac(x[off[k]:off[k + 1]], y[off[k]:off[k + 1]], K, S[k], max_sq_err=thr, success_prob=0.999, adaptive=adaptive,
+                          loss_kind=loss)
         assert best["best_h"][k] == e["best_h"] and best["iterations"][k] == e["iterations"], (k, n)
         assert np.array_equal(inl[ioff[k]:ioff[k + 1]], e["inliers"]), (k, n)
         if e["best_h"] >= 0:

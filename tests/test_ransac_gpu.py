@@ -520,3 +520,43 @@ def test_matrix_core_pretest_over_a_ragged_batch(ctx, oracle):
         if e["best_h"] >= 0:
             assert best["count"][k] == e["counts"][e["best_h"]], k
         assert np.array_equal(inl[ioff[k]:ioff[k + 1]], e["inliers"]), k
+
+
+@pytest.mark.parametrize("ratio,thr,n,H", [(0.15, 1.0, 5000, 1024), (0.5, 1.0, 3000, 512), (0.9, 4.0, 2100, 300), (0.3, 1e-2, 1999, 257),
+                                           (0.6, 1e4, 1500, 256), (1.0, 1.0, 777, 130)])
+def test_matrix_core_pretest_with_the_sampson_distance(ctx, oracle, ratio, thr, n, H):
+    """Sampson distance (extension): unsplit launches run a pre-test on the matrix cores too -- no inlier when
+    num^2 >= c^2 (|(E x1h)_01|^2 + 1.001 |x2h|^2) / f^2.  Per-row counts, error sums and the inlier list equal those
+    with the test off and the restatement's, also with observations at the epipoles, far outside the image and at
+    the origin."""
+    tv = synth.two_view(n, inlier_ratio=ratio, seed=2000 + n, noise_px=0.7)
+    x, y = tv["x"].copy(), tv["y"].copy()
+    S = synth.sample_table(n, H, seed=177 + H)
+    R, T = tv["R"], tv["T"]
+    e1, e2 = -R.T @ T, T
+    for k in range(10):
+        x[100 + k] = e1[:2] / e1[2] + (k % 5) * 1e-7
+        y[120 + k] = e2[:2] / e2[2] + (k % 7) * 1e-9
+    x[50] = [1e9, -1e9]
+    y[51] = [1e7, 2e7]
+    x[52] = y[52] = [0.0, 0.0]
+    x[53] = [40.0, -3.0]
+    y[53] = [-2.0, 30.0]
+    res = {}
+    ctx.set_option("ransac_split", 0)
+    try:
+        for name, mf, gib in (("mfma", 1, 64), ("mfma_blocks", 1, 0), ("off", 0, 64)):
+            ctx.set_option("ransac_mfma", mf)
+            ctx.set_option("ransac_mfma_ops_gib", gib)
+            res[name] = ctx.ransac_pair(x, y, tv["K"], S, max_sq_err=thr, adaptive=False, loss=capi.LOSS_SAMPSON)
+    finally:
+        ctx.set_option("ransac_split", 1)
+        ctx.set_option("ransac_mfma", 1)
+        ctx.set_option("ransac_mfma_ops_gib", 64)
+    for other in ("mfma_blocks", "off"):
+        assert np.array_equal(res["mfma"]["counts"], res[other]["counts"]), other
+        assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), res[other]["toterr"].view(np.uint64)), other
+        assert np.array_equal(res["mfma"]["inliers"], res[other]["inliers"]), other
+    exp = oracle.ransac(x, y, tv["K"], S, max_sq_err=thr, adaptive=False, loss_kind=capi.LOSS_SAMPSON)
+    assert np.array_equal(res["mfma"]["counts"], exp["counts"]) and np.array_equal(res["mfma"]["inliers"], exp["inliers"])
+    assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), np.asarray(exp["toterr"]).view(np.uint64))
