@@ -642,7 +642,7 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
     dev = torch.device(f"cuda:{local_rank}")
     K = synth.default_K()
 
-    def measure(pairs, distinct, ratio, adaptive, filt, steps, seed):
+    def measure(pairs, distinct, ratio, adaptive, filt, steps, seed, loss=0):
         xd, yd, sd = ransac_inputs(torch, dev, pairs, distinct, n, H, ratio, seed)
         off = np.arange(pairs + 1, dtype=np.int64) * n
         ctx.set_option("ransac_filter", filt)
@@ -651,7 +651,7 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
         def step():
             nonlocal batch
             batch = ctx.ransac_batch(off, None, None, K, None, H, max_sq_err=1.0, success_prob=0.999, adaptive=adaptive,
-                                     batch=batch, device_ptrs=(xd.data_ptr(), yd.data_ptr(), sd.data_ptr()))
+                                     batch=batch, device_ptrs=(xd.data_ptr(), yd.data_ptr(), sd.data_ptr()), loss=loss)
             ctx.synchronize()
 
         step()
@@ -719,6 +719,10 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
                                                "mean_iterations": float(np.mean(best2["iterations"])),
                                                "mean_best_inliers": float(np.mean(best2["count"]))}})
         out["where_a_model_is_found"] = rows
+        # extension (no counterpart in the reference): the Sampson distance as the loss, on the stress shape
+        el, kms, launches, best = measure(512, 64, 0.15, True, 1, 1, 91, loss=1)
+        out["sampson_distance_extension"] = {"pairs": 512, "inlier_ratio": 0.15, "hyps_per_s": round(512 * H / el, 1),
+                                             "score_kernel_ms": round(kms, 3), "mean_best_inliers": float(np.mean(best["count"]))}
     return out
 
 
