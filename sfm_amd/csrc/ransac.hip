@@ -495,7 +495,7 @@ __device__ __forceinline__ void svd3(const double E[3][3], double U[3][3], doubl
     }
 }
 
-__global__ __launch_bounds__(64) void ransac_fit_kernel(const RansacArgs g)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_fit_kernel(const RansacArgs g)
 {
     const int p = blockIdx.y;
     const int h = g.hBegin + blockIdx.x * 64 + threadIdx.x;
