@@ -2020,7 +2020,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                                            {res->stats.p, ci == 0 ? 4 * sizeof(u64) : 0}}));
         }
         const int nblk = chunkWorkCount[0][ci];
-        const int walkGrid = std::max(8, 4 * ctx->n_cus / 8 * 8); // grid of the passes that walk the work list
+        // Grid of the passes that walk the work list: as many blocks as the device holds of that kernel at once (its
+        // blocks per CU), so that all of them start together and share the items evenly -- with more, the late
+        // blocks run their whole share on a nearly empty device.  A multiple of 8 keeps a pair's items on one XCD.
+        auto walk_grid = [&](int blocksPerCu) { return std::max(8, blocksPerCu * ctx->n_cus / 8 * 8); };
         if (nblk > 0) {
             const bool cosine = metric != SFM_METRIC_DOT; // the L2 mode runs the cosine bound passes with its own per-pair bound
             const bool strictFirst = cosine || dotStrict;  // (the dot metric too, under a cosine bound from the images' largest norms)
@@ -2050,7 +2053,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                     hipLaunchKernelGGL(match_flood_probe_kernel, dim3(np), dim3(256), 0, st, g);
                 g.onlyFlagged = 3;
                 g.nWork = nblk;
-                hipLaunchKernelGGL(variant.strict16, dim3(std::min(nblk, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
+                hipLaunchKernelGGL(variant.strict16, dim3(std::min(nblk, walk_grid(3))), dim3(SIM_WAVES * 64), 0, st, g);
             }
             // Cosine: pairs whose slices overflowed, again, with the row-best filter in both
             // orientations.  Dot: every pair takes this path.
@@ -2064,9 +2067,10 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 g.work = workList[0];
                 g.nWork = chunkWorkCount[0][ci];
                 hipLaunchKernelGGL(match_col_bars_kernel<true>, dim3(8, np), dim3(256), 0, st, g);
-                hipLaunchKernelGGL(kSimRowMax, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
+                hipLaunchKernelGGL(kSimRowMax, dim3(std::min(g.nWork, walk_grid(3))), dim3(SIM_WAVES * 64), 0, st, g);
                 hipLaunchKernelGGL(match_col_bars_kernel<false>, dim3(8, np), dim3(256), 0, st, g);
-                hipLaunchKernelGGL(kSimBar, dim3(std::min(g.nWork, walkGrid)), dim3(SIM_WAVES * 64), 0, st, g);
+                hipLaunchKernelGGL(kSimBar, dim3(std::min(g.nWork, walk_grid(4))), // (two blocks per CU: two full rounds, which evens out the items' unequal cost)
+                                   dim3(SIM_WAVES * 64), 0, st, g);
                 g.gateMode = 2;
             }
             for (int o = 0; o < 2; o++) {
@@ -2074,7 +2078,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 g.work = workList[o];
                 if (!strictFirst && o == 0) SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.nWork = chunkWorkCount[o][ci];
-                hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(cosine ? std::min(g.nWork, walkGrid) : g.nWork),
+                hipLaunchKernelGGL(cosine ? kSimGeneral : kSimDot, dim3(cosine ? std::min(g.nWork, walk_grid(2)) : g.nWork),
                                    dim3(SIM_WAVES * 64), 0, st, g);
                 if (!strictFirst && o == 0) SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
             }
