@@ -10,6 +10,7 @@
 #include "sfm_amd_context.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace SfM::match
@@ -55,9 +56,32 @@ namespace SfM::match
         const size_t dim = keypoints1[0].descriptor.size();
         sfm_ctx *ctx = sfm_amd_adaptor::context();
         static thread_local sfm_amd_adaptor::PinnedTable tables[4]; // packed tables stay page-locked from call to call
+        // A video is matched frame i against i + 1, then i + 1 against i + 2 (scene.cpp:60): image A of a call is
+        // image B of the call before.  With SFM_AMD_REUSE_FRAMES=1 in the environment the caller promises that a
+        // keypoint vector seen again at the same address and size has not changed; the table packed for it last
+        // time becomes this call's table A, and the library (option "match_pair_reuse") takes it from the device.
+        static thread_local const Keypoint *lastB = nullptr;
+        static thread_local size_t lastCount = 0, lastDim = 0;
+        static const bool reuse = [] {
+            const char *v = std::getenv("SFM_AMD_REUSE_FRAMES");
+            return v && std::atoi(v) != 0;
+        }();
+        static thread_local bool optionSet = false;
+        if (reuse && !optionSet) {
+            if (sfm_ctx_set_option(ctx, "match_pair_reuse", 1) != SFM_OK) sfm_amd_adaptor::fail(ctx, SFM_ERR_INVALID_ARG, "sfm_ctx_set_option");
+            optionSet = true;
+        }
+        const bool sameA = reuse && keypoints1.data() == lastB && keypoints1.size() == lastCount && dim == lastDim;
+        lastB = nullptr;
+        if (sameA) {
+            std::swap(tables[0].p, tables[1].p);
+            std::swap(tables[0].cap, tables[1].cap);
+            std::swap(tables[2].p, tables[3].p);
+            std::swap(tables[2].cap, tables[3].cap);
+        }
         float *descA = tables[0].reserve<float>(ctx, keypoints1.size() * dim), *descB = tables[1].reserve<float>(ctx, keypoints2.size() * dim);
         double *ptsA = tables[2].reserve<double>(ctx, keypoints1.size() * 2), *ptsB = tables[3].reserve<double>(ctx, keypoints2.size() * 2);
-        pack(keypoints1, dim, descA, ptsA);
+        if (!sameA) pack(keypoints1, dim, descA, ptsA);
         pack(keypoints2, dim, descB, ptsB);
         const int capacity = static_cast<int>(std::min(keypoints1.size(), keypoints2.size()));
         std::vector<int32_t> pairs(2 * static_cast<size_t>(capacity));
@@ -66,6 +90,9 @@ namespace SfM::match
                                       descB, ptsB, static_cast<int>(keypoints2.size()), static_cast<int>(dim), metric,
                                       options.threshold, options.maxDistancePxSquared, pairs.data(), capacity, &count, nullptr, nullptr);
         if (rc != SFM_OK) sfm_amd_adaptor::fail(ctx, rc, "sfm_match_pair");
+        lastB = keypoints2.data();
+        lastCount = keypoints2.size();
+        lastDim = dim;
         result.reserve(count);
         for (int k = 0; k < count; k++) result.emplace_back(pairs[2 * k], pairs[2 * k + 1]);
         return result;

@@ -526,6 +526,16 @@ def bench_pipeline(ctx, args):
     # the same tables in page-locked memory (sfm_host_alloc), where an adaptor that packs Keypoints can keep them
     qA, rA, qB, rB = (ctx.pinned_like(a) for a in (dA, pA, dB, pB))
     match_pinned_ms, _ = per_call_ms(lambda: ctx.match_pair(qA, rA, qB, rB, threshold=0.95, max_dist_sq=100.0 * 100.0))
+    # a video's order (scene.cpp:60: image A of a call is image B of the call before) with the caller's promise that
+    # a table seen again at the same address has not changed: that image comes from the device
+    ctx.set_option("match_pair_reuse", 1)
+    turn = [0]
+    def shared_frame_call():
+        turn[0] ^= 1
+        return (ctx.match_pair(qA, rA, qB, rB, threshold=0.95, max_dist_sq=100.0 * 100.0) if turn[0] else
+                ctx.match_pair(qB, rB, qA, rA, threshold=0.95, max_dist_sq=100.0 * 100.0))
+    match_shared_ms, _ = per_call_ms(shared_frame_call)
+    ctx.set_option("match_pair_reuse", 0)
     # the same call with MATCHING_OPTIONS' defaults (match.hpp:59-60: threshold 0.5, gate 10000^2): most cells clear
     # the threshold, the strict lists flood, and the two-phase sweeps decide
     match_default_ms, _ = per_call_ms(lambda: ctx.match_pair(qA, rA, qB, rB, threshold=0.5, max_dist_sq=1e8))
@@ -558,6 +568,7 @@ def bench_pipeline(ctx, args):
             "match_pair_ms": round(match_call_ms, 3), "match_pair_ms_tables_in_page_locked_memory": round(match_pinned_ms, 3),
             "match_pair_ms_byte_tables_in_page_locked_memory": None if match_u8_ms is None else round(match_u8_ms, 3),
             "match_pair_ms_reference_default_options_page_locked": round(match_default_ms, 3),
+            "match_pair_ms_shared_frame_kept_on_device_page_locked": round(match_shared_ms, 3),
             "features": int(counts[0]),
             "ransac_pair_ms": round(ransac_call_ms, 3), "correspondences": int(len(x0)), "hypotheses": H,
             "ransac_iterations": int(rr["iterations"]), "ransac_inliers": int(len(rr["inliers"])),

@@ -104,6 +104,14 @@ const char *sfm_version(void);
  * norm of B), which is tight for descriptors of unit norm, default; 0 = the
  * bound is scaled by the two norms cell by cell for every pair; results are
  * identical),
+ * "match_pair_reuse" (0 = every sfm_match_pair / sfm_match_pair_u8 call uploads
+ * both images, default; 1 = the caller promises that a descriptor table and a
+ * point table passed again under the same addresses, with the same row count
+ * and descriptor length, have not changed since the last call: when image A
+ * of a call is image B of the call before - the reference matches frame i
+ * against i + 1 and then i + 1 against i + 2, scene.cpp:60 - it is copied from
+ * the device instead of uploaded; results are identical when the promise
+ * holds),
  * "cand_observe" (1 = a batch call of several chunks runs a first
  * chunk of at most 128 pairs with "cand_capacity" slots per pair, looks at how
  * far the lists filled and sizes the lists of the other chunks from that,

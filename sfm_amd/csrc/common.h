@@ -26,6 +26,7 @@ struct sfm_ctx {
     int match_two_phase = 1;         // 0: flagged pairs always take the filtered pass with running row bounds
     int match_flood_probe = 1;       // 0: pairs the int8 bound flooded always try the fp16 strict pass before the filtered ones
     int match_dot_strict = 1;        // 0: the dot metric scales the bound by the norms cell by cell for every pair
+    int match_pair_reuse = 0;        // 1: the single-pair matcher takes image A from the device when it is the last call's image B (same host addresses and sizes: the caller promises the tables have not changed)
     int cand_observe = 1;            // calls of several chunks size the candidate lists of later chunks from the first one
     int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
@@ -54,6 +55,7 @@ struct sfm_ctx {
     sfm_ransac_batch *pair_batch = nullptr; // device buffers of the single-pair RANSAC entry points
     sfm_imageset *pair_set = nullptr;       // and of the single-pair matcher
     sfm_match_result *pair_result = nullptr;
+    struct PairKeep *pair_keep = nullptr;   // image B of the last single-pair matcher call (option match_pair_reuse)
     int64_t chain_table_entries = (int64_t)1 << 26;
     // single-pair RANSAC: seed of the sample table the library draws when the caller passes none (0 = from the
     // clock, as the reference does, RANSAC.cpp:170), and the wall-clock cap of RANSAC_OPTIONS::maxTimeMs

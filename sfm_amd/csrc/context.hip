@@ -120,6 +120,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->match_flood_probe = value != 0;
     } else if (!strcmp(key, "match_dot_strict")) {
         ctx->match_dot_strict = value != 0;
+    } else if (!strcmp(key, "match_pair_reuse")) {
+        ctx->match_pair_reuse = value != 0;
     } else if (!strcmp(key, "cand_observe")) {
         ctx->cand_observe = value != 0;
     } else if (!strcmp(key, "match_overlap")) {

@@ -1451,6 +1451,21 @@ struct TwoParts {
     const float *desc[2];
     const double *pts[2];
     const unsigned char *desc_u8[2] = {nullptr, nullptr}; // byte-valued tables instead of desc (both or neither)
+    // image 0 is already on the device (descriptors in the form the host tables have, and points): copied
+    // from there instead of uploaded
+    const void *dev_desc0 = nullptr;
+    const double *dev_pts0 = nullptr;
+};
+
+// Image B of the last single-pair matcher call as it was uploaded.  The reference matches frame i against
+// frame i + 1 and then frame i + 1 against frame i + 2 (scene.cpp:60), so B of one call is A of the next; a
+// caller that promises not to change a table between the two calls saves that upload.
+struct PairKeep {
+    DevBuf desc, pts;
+    const void *host_desc = nullptr;
+    const double *host_pts = nullptr;
+    int n = 0, dim = 0;
+    bool bytes = false;
 };
 
 // reuse: slot holding a set built earlier by this function from host tables, whose device buffers are
@@ -1535,7 +1550,12 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
             if (parts_u8) SET_HIP(s->desc8u.reserve((size_t)(r32 ? r32 : 1) * dim));
             for (int k = 0; k < 2 && k < n_images; k++) {
                 const size_t nk = (size_t)counts[k];
-                if (nk) {
+                if (nk && k == 0 && parts->dev_desc0) {
+                    void *dst = parts_u8 ? s->desc8u.p : s->desc32.p;
+                    SET_HIP(hipMemcpyAsync(dst, parts->dev_desc0, nk * dim * (parts_u8 ? 1 : sizeof(float)), hipMemcpyDeviceToDevice,
+                                           ctx->stream));
+                    SET_HIP(hipMemcpyAsync(s->pts.p, parts->dev_pts0, nk * 2 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                } else if (nk) {
                     if (parts_u8) // a quarter of the bytes; widened below
                         SET_HIP(hipMemcpyAsync(s->desc8u.as<unsigned char>() + (size_t)row * dim, parts->desc_u8[k], nk * dim,
                                                hipMemcpyHostToDevice, ctx->stream));
@@ -2298,12 +2318,35 @@ static int match_pair_impl(sfm_ctx *ctx, int algorithm, const void *descA, const
         parts.desc[0] = static_cast<const float *>(descA);
         parts.desc[1] = static_cast<const float *>(descB);
     }
+    PairKeep *keep = ctx->pair_keep;
+    if (ctx->match_pair_reuse && keep && nA > 0 && keep->host_desc == descA && keep->host_pts == ptsA && keep->n == nA &&
+        keep->dim == dim && keep->bytes == bytes) {
+        parts.dev_desc0 = keep->desc.p;
+        parts.dev_pts0 = keep->pts.as<double>();
+    }
+    if (keep) keep->host_desc = nullptr; // whatever happens below, the kept table is not offered twice
     sfm_imageset *set = nullptr;
     // Nothing waits for the device between the upload and the copy of the results: the set is built without
     // its host-side flags, and the result kept in the context is idle because every call ends with a wait.
     int rc = imageset_build(ctx, 2, counts, nullptr, nullptr, dim, false, &set, nullptr, &ctx->pair_set, &parts, true);
     if (rc != SFM_OK) return rc;
     ctx->pair_set = set;
+    if (ctx->match_pair_reuse && nB > 0) {
+        if (!keep) keep = ctx->pair_keep = new (std::nothrow) PairKeep();
+        if (!keep) SFM_FAIL(ctx, SFM_ERR_OOM, "match: host allocation failed");
+        const size_t bDesc = (size_t)nB * dim * (bytes ? 1 : sizeof(float)), bPts = (size_t)nB * 2 * sizeof(double);
+        SFM_HIP(ctx, keep->desc.reserve(bDesc));
+        SFM_HIP(ctx, keep->pts.reserve(bPts));
+        const void *src = bytes ? (const void *)(set->desc8u.as<unsigned char>() + (size_t)nA * dim)
+                                : (const void *)(set->desc32.as<float>() + (size_t)nA * dim);
+        SFM_HIP(ctx, hipMemcpyAsync(keep->desc.p, src, bDesc, hipMemcpyDeviceToDevice, ctx->stream));
+        SFM_HIP(ctx, hipMemcpyAsync(keep->pts.p, set->pts.as<double>() + (size_t)nA * 2, bPts, hipMemcpyDeviceToDevice, ctx->stream));
+        keep->host_desc = descB;
+        keep->host_pts = ptsB;
+        keep->n = nB;
+        keep->dim = dim;
+        keep->bytes = bytes;
+    }
     const int32_t pl[2] = {0, 1};
     rc = match_batch_impl(ctx, set, pl, 1, metric, threshold, max_distance_px_squared, &ctx->pair_result, true, 0.0f, true);
     if (rc != SFM_OK) {
@@ -2357,8 +2400,14 @@ void sfm_pair_match_free(sfm_ctx *ctx)
 {
     if (ctx->pair_result) sfm_match_result_destroy(ctx->pair_result);
     if (ctx->pair_set) sfm_imageset_destroy(ctx->pair_set);
+    if (ctx->pair_keep) {
+        ctx->pair_keep->desc.release();
+        ctx->pair_keep->pts.release();
+        delete ctx->pair_keep;
+    }
     ctx->pair_result = nullptr;
     ctx->pair_set = nullptr;
+    ctx->pair_keep = nullptr;
 }
 
 extern "C" int64_t sfm_match_result_device_bytes(const sfm_match_result *r)

@@ -5,6 +5,11 @@
 //   test_frontend --lifetime        (makes the thread's context and exits without releasing anything)
 //   test_frontend --time <case.bin> (wall time of match() and RANSAC() per call, as a caller of the reference sees them:
 //                                    packing of the keypoints, upload, kernels, download and the result vector included)
+//   test_frontend --sequence <case.bin> (three frames - A, B and A's keypoints in reverse order - matched in the order
+//                                    of a video, B of one call being A of the next, and once out of that order;
+//                                    every list is compared with the CPU path's when the frames are small, and the
+//                                    time per call is printed.  With SFM_AMD_REUSE_FRAMES=1 the adaptor and the
+//                                    library skip the packing and the upload of the shared frame)
 // case.bin: int32 nA, nB, dim; float thr, gate; float descA[nA*dim]; double ptsA[2nA]; descB; ptsB;
 //           int32 n, maxIter; double maxSqErr, successProb; double K[9]; double x[2n]; double y[2n]
 // out.bin:  int32 nMatches; int32 pairs[2*nMatches]; int32 nInliers; int32 inliers[nInliers];
@@ -81,8 +86,9 @@ int main(int argc, char **argv)
 {
     if (argc == 2 && !strcmp(argv[1], "--lifetime")) return lifetime();
     const bool timing = argc == 3 && !strcmp(argv[1], "--time");
+    const bool sequence = argc == 3 && !strcmp(argv[1], "--sequence");
     if (argc != 3) return 2;
-    FILE *f = fopen(argv[timing ? 2 : 1], "rb");
+    FILE *f = fopen(argv[timing || sequence ? 2 : 1], "rb");
     if (!f) return 2;
     int32_t nA, nB, dim;
     float thr, gate;
@@ -112,6 +118,28 @@ int main(int argc, char **argv)
     match::MATCHING_OPTIONS mo;
     mo.threshold = thr;
     mo.maxDistancePxSquared = gate;
+    if (sequence) {
+        std::vector<Keypoint> kC(kA.rbegin(), kA.rend());
+        const std::vector<Keypoint> *frames[3] = {&kA, &kB, &kC};
+        const int order[5][2] = {{0, 1}, {1, 2}, {0, 2}, {2, 1}, {1, 0}}; // calls 2, 4 and 5 continue the call before them
+        const bool check = (double)nA * nB <= 2e6;
+        double ms = 0;
+        size_t total = 0;
+        for (int round = 0; round < (check ? 2 : 12); round++)
+            for (int c = 0; c < 5; c++) {
+                const auto &k1 = *frames[order[c][0]], &k2 = *frames[order[c][1]];
+                const auto t0 = std::chrono::steady_clock::now();
+                const auto got = match::match(k1, k2, mo);
+                if (round >= 2 || check) ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                total += got.size();
+                if (check && got != match::matchTwoSided(k1, k2, mo)) {
+                    fprintf(stderr, "sequence: call %d of round %d differs from the CPU path\n", c, round);
+                    return 7;
+                }
+            }
+        printf("sequence: %.3f ms per call (%d x %d keypoints, %zu matches in all)\n", ms / (check ? 10 : 50), nA, nB, total);
+        return 0;
+    }
     if (timing) {
         solve::RANSAC_OPTIONS ro;
         ro.maxIter = maxIter;

@@ -104,3 +104,34 @@ def test_cpp_call_times(tmp_path):
     import re
     t = [float(v) for v in re.findall(r"([0-9.]+) ms per call", r.stdout)]
     assert len(t) == 2 and max(t) < 50.0
+
+
+def _write_case(path, dA, pA, dB, pB, thr, gate, tv, max_iter):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iiiff", len(dA), len(dB), dA.shape[1], thr, gate))
+        for a in (dA.astype(np.float32), pA.astype(np.float64), dB.astype(np.float32), pB.astype(np.float64)):
+            f.write(a.tobytes())
+        f.write(struct.pack("<iidd", len(tv["x"]), max_iter, 1.0, 0.999))
+        f.write(np.asfortranarray(tv["K"]).reshape(-1, order="F").astype(np.float64).tobytes())
+        f.write(tv["x"].astype(np.float64).tobytes())
+        f.write(tv["y"].astype(np.float64).tobytes())
+
+
+@pytest.mark.parametrize("reuse", ["0", "1"])
+def test_cpp_frame_sequence(tmp_path, reuse):
+    """match() over three frames in a video's order (B of one call is A of the next, scene.cpp:60) and once out of
+    it, with and without SFM_AMD_REUSE_FRAMES: the binary compares every list with the adaptor's CPU path (small
+    frames), then times the same calls at 8192 keypoints per frame (printed with pytest -s)."""
+    tv = synth.two_view(64, inlier_ratio=0.8, seed=5)
+    d, p, _ = synth.image_set(2, 700, seed=91)
+    small = str(tmp_path / "seq_small.bin")
+    _write_case(small, d[:650], p[:650], d[700:], p[700:], 0.9, 1e8, tv, 64)
+    env = dict(os.environ, SFM_AMD_REUSE_FRAMES=reuse)
+    r = subprocess.run([EXE, "--sequence", small], capture_output=True, text=True, timeout=100, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    d, p, counts, _ = synth.frame_sequence(2, 8192, seed=4242)
+    big = str(tmp_path / "seq_big.bin")
+    _write_case(big, d[:counts[0]], p[:counts[0]], d[counts[0]:], p[counts[0]:], 0.95, 1e4, tv, 64)
+    r = subprocess.run([EXE, "--sequence", big], capture_output=True, text=True, timeout=100, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    print("SFM_AMD_REUSE_FRAMES=" + reuse, r.stdout.strip())

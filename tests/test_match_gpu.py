@@ -595,3 +595,43 @@ def test_dot_metric_through_the_strict_passes(ctx, oracle, spread):
                                  threshold=0.9, max_dist_sq=1e8, metric=1)
         assert np.array_equal(pairs[off[k]:off[k + 1]], exp), k
     s.close()
+
+
+@pytest.mark.parametrize("as_bytes", [False, True])
+def test_pair_calls_reuse_the_shared_frame(ctx, oracle, as_bytes):
+    """Option match_pair_reuse: image A of a call is taken from the device when it is the last call's image B (same
+    host tables).  A video's order (scene.cpp:60: frame i against i + 1, then i + 1 against i + 2), one call out of
+    that order, frames of unequal sizes and a table of another size at a reused address: every list equals the
+    restatement's and the lists of the same calls with the option off."""
+    d, p, _ = synth.image_set(4, 900, seed=77)
+    sizes = [900, 640, 900, 777]
+    frames = []
+    for k, n in enumerate(sizes):
+        dk = np.ascontiguousarray(d[900 * k:900 * k + n])
+        if as_bytes:
+            dk = np.ascontiguousarray(np.clip(np.rint(dk * 400.0), 0, 255).astype(np.uint8))
+        frames.append((dk, np.ascontiguousarray(p[900 * k:900 * k + n])))
+    order = [(0, 1), (1, 2), (2, 3), (0, 3), (3, 2), (2, 1), (1, 0), (0, 1)]
+
+    def run():
+        return [ctx.match_pair(frames[a][0], frames[a][1], frames[b][0], frames[b][1], threshold=0.9, max_dist_sq=1e8)
+                for a, b in order]
+
+    plain = run()
+    ctx.set_option("match_pair_reuse", 1)
+    try:
+        kept = run()
+        # the promise covers unchanged tables only: a changed table must come under another address, and a table of
+        # another size at the same address is not taken for the kept one
+        other = (frames[1][0][:500], frames[1][1][:500])
+        kept_other = ctx.match_pair(other[0], other[1], frames[2][0], frames[2][1], threshold=0.9, max_dist_sq=1e8)
+    finally:
+        ctx.set_option("match_pair_reuse", 0)
+    for (a, b), x, y in zip(order, plain, kept):
+        exp, _, _ = oracle.match(frames[a][0].astype(np.float32), frames[a][1], frames[b][0].astype(np.float32), frames[b][1],
+                                 threshold=0.9, max_dist_sq=1e8)
+        assert np.array_equal(x, exp) and np.array_equal(y, exp), (a, b)
+        assert len(exp) > 10
+    exp, _, _ = oracle.match(other[0].astype(np.float32), other[1], frames[2][0].astype(np.float32), frames[2][1], threshold=0.9,
+                             max_dist_sq=1e8)
+    assert np.array_equal(kept_other, exp)
