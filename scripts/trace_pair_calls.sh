@@ -18,8 +18,8 @@ for f in glob.glob(f'gpurun_out/trace_pair_{w}/*/*_memory_copy_trace.csv'):
     for r in csv.DictReader(open(f)):
         ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', r.get('Kind', ''))))
 ev.sort()
-# a call begins with the first host-to-device copy after a device-to-host copy and ends with its last device-to-host copy
-starts = [i for i, e in enumerate(ev) if 'HOST_TO_DEVICE' in e[2] and i > 0 and 'DEVICE_TO_HOST' in ev[i - 1][2]]
+# a call begins with the first event after a device-to-host copy and ends with its last device-to-host copy
+starts = [i for i, e in enumerate(ev) if 'DEVICE_TO_HOST' not in e[2] and i > 0 and 'DEVICE_TO_HOST' in ev[i - 1][2]]
 call = ev[starts[-1]:]
 period_from = ev[starts[-2]][0]
 t0 = call[0][0]

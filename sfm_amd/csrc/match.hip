@@ -93,59 +93,81 @@ __device__ __forceinline__ unsigned wave_max_u(unsigned v)
 // bbox[4 * image ..]: ordered keys of max x, max -x, max y, max -y over the image's points (as floats, which is
 // what the pixel gate's "can it exclude anything at all" test needs); an image with a point that is not finite
 // gets IMG_PTS_WILD instead.
+// Eight lanes per row, sixteen elements each (a wave takes eight rows): the divisions, conversions and checks of a
+// row are spread over its lanes, and only the squared norm runs element after element, handed from lane to
+// lane, because its rounding must follow the reference's loop (match.hpp:36-45).
+#define INGEST_LANES 8
+#define INGEST_ELEMS (KDIM / INGEST_LANES)
+#define INGEST_WAVES 8 // waves per block
 template <bool VEC>
-__global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+__global__ __launch_bounds__(64 * INGEST_WAVES) void ingest_rows_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
                                                          int dim, float *__restrict__ norms, float *__restrict__ norms2,
                                                          int *__restrict__ imageFlags, int *__restrict__ stats,
                                                          int *__restrict__ normRange, _Float16 *__restrict__ desc16,
                                                          const double2 *__restrict__ pts, unsigned *__restrict__ bbox)
 {
+    static_assert(INGEST_ELEMS == 16, "two half8 stores per lane");
+    constexpr int ROWS = 64 * INGEST_WAVES / INGEST_LANES; // rows per block
     const ImageRec im = images[blockIdx.y];
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.x * 64 >= im.n) return;
+    const int sub = threadIdx.x & (INGEST_LANES - 1);
+    const int r = blockIdx.x * ROWS + (threadIdx.x / INGEST_LANES);
+    if (blockIdx.x * ROWS >= im.n) return;
     const bool valid = r < im.n;
-    const float *a = desc32 + (size_t)(im.row32 + (valid ? r : 0)) * dim;
-    float v[KDIM];
+    const int k0 = sub * INGEST_ELEMS;
+    const float *a = desc32 + (size_t)(im.row32 + (valid ? r : 0)) * dim + k0;
+    float v[INGEST_ELEMS];
     if constexpr (VEC) { // dim is a multiple of four: rows are 16-byte aligned
 #pragma unroll
-        for (int k = 0; k < KDIM; k += 4) {
+        for (int k = 0; k < INGEST_ELEMS; k += 4) {
             float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (k < dim) q = *reinterpret_cast<const float4 *>(a + k);
+            if (k0 + k < dim) q = *reinterpret_cast<const float4 *>(a + k);
             v[k] = q.x, v[k + 1] = q.y, v[k + 2] = q.z, v[k + 3] = q.w;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < KDIM; k++) v[k] = (k < dim) ? a[k] : 0.0f;
+        for (int k = 0; k < INGEST_ELEMS; k++) v[k] = (k0 + k < dim) ? a[k] : 0.0f;
     }
     // (the zeros beyond dim change nothing below: x + 0 = x, max(x, 0) = x for x >= 0, and 0 is a byte)
-    float normA = 0.0f;
+    float sq[INGEST_ELEMS];
     bool bytes = true;
 #pragma unroll
-    for (int k = 0; k < KDIM; k++) {
-        normA = __fadd_rn(normA, __fmul_rn(v[k], v[k]));
+    for (int k = 0; k < INGEST_ELEMS; k++) {
+        sq[k] = __fmul_rn(v[k], v[k]);
         bytes = bytes && v[k] >= 0.0f && v[k] <= 255.0f && v[k] == floorf(v[k]);
+    }
+    // The sum in element order: in turn g every lane adds its squares to the sum so far, and the result of the
+    // row's lane g - the only one whose squares belong there - is what all of the row's lanes go on with.
+    float normA = 0.0f;
+#pragma unroll
+    for (int g = 0; g < INGEST_LANES; g++) {
+        float mine = normA;
+#pragma unroll
+        for (int k = 0; k < INGEST_ELEMS; k++) mine = __fadd_rn(mine, sq[k]);
+        normA = __shfl(mine, (int)(threadIdx.x & ~(INGEST_LANES - 1)) | g, 64);
     }
     // sqrtf, not __fsqrt_rn: the latter compiles to the bare v_sqrt_f32 (1 ulp); sqrtf is correctly rounded
     // under -fhip-fp32-correctly-rounded-divide-sqrt, like std::sqrt on the host (match.hpp:45)
     const float s = sqrtf(normA);
     const bool ok = (s >= 1e-12f) && (s <= 1e12f);
     float mx = 0.0f, l1 = 0.0f;
-    _Float16 *out = desc16 + (size_t)(im.row16 + r) * KDIM;
+    _Float16 *out = desc16 + (size_t)(im.row16 + r) * KDIM + k0;
 #pragma unroll
-    for (int k0 = 0; k0 < KDIM; k0 += 8) {
+    for (int e0 = 0; e0 < INGEST_ELEMS; e0 += 8) {
         half8 h;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float q = ok ? __fdiv_rn(v[k0 + e], s) : 0.0f;
+            const float q = ok ? __fdiv_rn(v[e0 + e], s) : 0.0f;
             h[e] = (_Float16)q;
             mx = fmaxf(mx, fabsf(q));
             l1 += fabsf(q);
         }
-        if (valid) *reinterpret_cast<half8 *>(out + k0) = h;
+        if (valid) *reinterpret_cast<half8 *>(out + e0) = h;
     }
+#pragma unroll
+    for (int d = 1; d < INGEST_LANES; d <<= 1) l1 += __shfl_xor(l1, d, 64); // the row's sum of magnitudes
     int f = 0;
     unsigned bx[4] = {0, 0, 0, 0};
-    if (valid) {
+    if (valid && sub == 0) {
         const double2 pt = pts[im.row32 + r];
         const float px = (float)pt.x, py = (float)pt.y;
         if (fabsf(px) <= 3.0e38f && fabsf(py) <= 3.0e38f) { // (false for NaN too)
@@ -153,10 +175,10 @@ __global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict
         } else {
             f |= IMG_PTS_WILD;
         }
-    }
-    if (valid) {
         norms[im.row32 + r] = s;
         norms2[im.row32 + r] = normA; // the squared norm as the reference's loop accumulates it (L2 mode)
+    }
+    if (valid) {
         f |= bytes ? 0 : IMG_NOT_U8;
         if (!ok) {
             f |= IMG_WILD_DOT;
@@ -173,15 +195,31 @@ __global__ __launch_bounds__(64) void ingest_rows_kernel(const float *__restrict
     for (int d = 32; d >= 1; d >>= 1) wF |= __shfl_xor(wF, d, 64);
 #pragma unroll
     for (int e = 0; e < 4; e++) bx[e] = wave_max_u(bx[e]);
-    if (threadIdx.x == 0) {
+    // One set of atomics per block: the per-image words share a cache line, and atomics on one line are
+    // served one after the other, so their number - not the arithmetic above - is what a small launch waits for.
+    __shared__ unsigned red[INGEST_WAVES][9];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (bx[e]) atomicMax(&bbox[4 * blockIdx.y + e], bx[e]);
-        if (wMx) atomicMax(&stats[2 * blockIdx.y], wMx);
-        if (wL1) atomicMax(&stats[2 * blockIdx.y + 1], wL1);
-        if (wLo) atomicMax(&normRange[2 * blockIdx.y], wLo);
-        if (wHi) atomicMax(&normRange[2 * blockIdx.y + 1], wHi);
-        if (wF) atomicOr(&imageFlags[blockIdx.y], wF);
+        for (int e = 0; e < 4; e++) red[wave][e] = bx[e];
+        red[wave][4] = (unsigned)wMx, red[wave][5] = (unsigned)wL1, red[wave][6] = (unsigned)wLo, red[wave][7] = (unsigned)wHi;
+        red[wave][8] = (unsigned)wF;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        unsigned v9 = 0; // (every word is non-negative as an int, so unsigned and signed maxima agree)
+#pragma unroll
+        for (int w = 0; w < INGEST_WAVES; w++) v9 = threadIdx.x == 8 ? (v9 | red[w][threadIdx.x]) : max(v9, red[w][threadIdx.x]);
+        const int e = threadIdx.x;
+        if (e < 4) {
+            if (v9) atomicMax(&bbox[4 * blockIdx.y + e], v9);
+        } else if (e < 6) {
+            if (v9) atomicMax(&stats[2 * blockIdx.y + (e - 4)], (int)v9);
+        } else if (e < 8) {
+            if (v9) atomicMax(&normRange[2 * blockIdx.y + (e - 6)], (int)v9);
+        } else if (v9) {
+            atomicOr(&imageFlags[blockIdx.y], (int)v9);
+        }
     }
 }
 
@@ -1592,8 +1630,9 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     if (n_images > 0 && maxN > 0) {
         SET_HIP(hipMemcpyAsync(s->imageRecs.p, s->images.data(), (size_t)n_images * sizeof(ImageRec),
                                hipMemcpyHostToDevice, ctx->stream));
-        dim3 g1((maxN + 63) / 64, n_images);
-        hipLaunchKernelGGL(((dim & 3) == 0 ? ingest_rows_kernel<true> : ingest_rows_kernel<false>), g1, dim3(64), 0, ctx->stream,
+        const int rowsPerBlock = 64 * INGEST_WAVES / INGEST_LANES;
+        dim3 g1((maxN + rowsPerBlock - 1) / rowsPerBlock, n_images);
+        hipLaunchKernelGGL(((dim & 3) == 0 ? ingest_rows_kernel<true> : ingest_rows_kernel<false>), g1, dim3(64 * INGEST_WAVES), 0, ctx->stream,
                            s->desc32.as<float>(), s->imageRecs.as<ImageRec>(), dim, s->norms.as<float>(), s->norms2.as<float>(),
                            imageFlags, s->imageStats.as<int>(), s->imageStats.as<int>() + 2 * nImg, s->desc16.as<_Float16>(),
                            s->pts.as<double2>(), s->imageStats.as<unsigned>() + 5 * nImg);
