@@ -403,7 +403,10 @@ class Context:
     # ---- matching -------------------------------------------------------------------------
     def match_pair(self, descA, ptsA, descB, ptsB, threshold=0.5, max_dist_sq=1e8, metric=METRIC_COSINE,
                    algorithm=MATCH_TWO_SIDED, return_best=False):
-        """SfM::match::match for one pair.  Tables of dtype uint8 (both) go through sfm_match_pair_u8."""
+        """SfM::match::match for one pair.  Tables of dtype uint8 (both) go through sfm_match_pair_u8.
+        With the option "match_pair_reuse" the library recognises a table by its address: pass arrays that are
+        already contiguous and of the call's dtype (float32 or uint8 descriptors, float64 points), so that no
+        temporary copy stands in for them, and do not change them between calls."""
         descA, descB = np.asarray(descA), np.asarray(descB)
         as_bytes = descA.dtype == np.uint8 and descB.dtype == np.uint8
         descA = np.ascontiguousarray(descA, np.uint8 if as_bytes else np.float32)
