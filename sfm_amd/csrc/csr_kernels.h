@@ -15,8 +15,9 @@ namespace {
 // in flight at a time (the row key leads to the column key: two dependent loads per row).
 // offsetsOut / totalOut (WRITE only, either may be null): a launch over a single pair needs no counting pass and
 // no scan; it writes offsetsOut[p + 1] = offsets[p] + count and totalOut[0] = count itself.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__restrict__ pairs,
+// WAVES: waves per block (a launch over one pair has one block only and takes sixteen).
+template <bool WRITE, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void match_mutual_kernel(const PairRec *__restrict__ pairs,
                                                            const u64 *__restrict__ best,
                                                            int *__restrict__ counts,
                                                            const int64_t *__restrict__ offsets,
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__rest
                                                            int64_t *__restrict__ totalOut)
 {
     constexpr int U = 4;
-    __shared__ int waveCnt[U][4];
+    constexpr int T = 64 * WAVES;
+    __shared__ int waveCnt[U][WAVES];
     const int p = blockIdx.x;
     const PairRec pr = pairs[p];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,13 +38,13 @@ __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__rest
     const int64_t first = WRITE ? offsets[p] : 0;
     int2 *dst = WRITE ? out + first : nullptr;
     int running = 0;
-    for (int base = 0; base < pr.nA; base += 256 * U) {
+    for (int base = 0; base < pr.nA; base += T * U) {
         u64 kr[U], kc[U];
         int j[U], prefix[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i = base + u * 256 + tid;
+            const int i = base + u * T + tid;
             kr[u] = (i < pr.nA) ? rowKey[i] : 0;
         }
 #pragma unroll
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__rest
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i = base + u * 256 + tid;
+            const int i = base + u * T + tid;
             ok[u] = kc[u] != 0 && (int)(0xFFFFFFFFu - (unsigned)kc[u]) == i;
             if (WRITE && m1out && i < pr.nA) m1out[i] = j[u];
             const u64 mask = __builtin_amdgcn_ballot_w64(ok[u]);
@@ -64,11 +66,11 @@ __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__rest
         for (int u = 0; u < U; u++) {
             int off = running, tot = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < WAVES; k++) {
                 if (k < wave) off += waveCnt[u][k];
                 tot += waveCnt[u][k];
             }
-            if (WRITE && ok[u]) dst[off + prefix[u]] = make_int2(base + u * 256 + tid, j[u]);
+            if (WRITE && ok[u]) dst[off + prefix[u]] = make_int2(base + u * T + tid, j[u]);
             running += tot;
         }
         __syncthreads();
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void match_mutual_kernel(const PairRec *__rest
         if (totalOut) totalOut[0] = running;
     }
     if (WRITE && m2out) {
-        for (int j2 = tid; j2 < pr.nB; j2 += 256) {
+        for (int j2 = tid; j2 < pr.nB; j2 += T) {
             const u64 k2 = colKey[j2];
             m2out[j2] = k2 ? (int)(0xFFFFFFFFu - (unsigned)k2) : -1;
         }

@@ -1586,7 +1586,12 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         } else if (parts) {
             int64_t row = 0;
             if (parts_u8) SET_HIP(s->desc8u.reserve((size_t)(r32 ? r32 : 1) * dim));
+            // The second image goes up on a stream of its own: copies queued on one stream start one after the
+            // other with a pause in between, on two streams they share the link without one.  (The device is
+            // idle here: every single-pair call ends with a wait.)
+            const bool twoStreams = ctx->stream3 && ctx->match_overlap && n_images == 2 && counts[0] > 0 && counts[1] > 0;
             for (int k = 0; k < 2 && k < n_images; k++) {
+                const hipStream_t upk = (k == 1 && twoStreams) ? ctx->stream3 : ctx->stream;
                 const size_t nk = (size_t)counts[k];
                 if (nk && k == 0 && parts->dev_desc0) {
                     void *dst = parts_u8 ? s->desc8u.p : s->desc32.p;
@@ -1596,14 +1601,18 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
                 } else if (nk) {
                     if (parts_u8) // a quarter of the bytes; widened below
                         SET_HIP(hipMemcpyAsync(s->desc8u.as<unsigned char>() + (size_t)row * dim, parts->desc_u8[k], nk * dim,
-                                               hipMemcpyHostToDevice, ctx->stream));
+                                               hipMemcpyHostToDevice, upk));
                     else
                     SET_HIP(hipMemcpyAsync(s->desc32.as<float>() + (size_t)row * dim, parts->desc[k], nk * dim * sizeof(float),
-                                           hipMemcpyHostToDevice, ctx->stream));
+                                           hipMemcpyHostToDevice, upk));
                     SET_HIP(hipMemcpyAsync(s->pts.as<double>() + (size_t)row * 2, parts->pts[k], nk * 2 * sizeof(double),
-                                           hipMemcpyHostToDevice, ctx->stream));
+                                           hipMemcpyHostToDevice, upk));
                 }
                 row += counts[k];
+            }
+            if (twoStreams) {
+                SET_HIP(hipEventRecord(ctx->ev[6], ctx->stream3));
+                SET_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev[6], 0));
             }
             if (parts_u8 && r32 > 0) {
                 const int64_t n = r32 * dim;
@@ -2191,7 +2200,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         }
         // (the scan continues the offsets of the chunk before: same stream, in order)
         if (np == 1) { // one pair: its list starts at the offset before it, no counting pass and no scan
-            hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(1), dim3(256), 0, st, g.pairs, g.best, (int *)nullptr,
+            hipLaunchKernelGGL((match_mutual_kernel<true, 16>), dim3(1), dim3(1024), 0, st, g.pairs, g.best, (int *)nullptr,
                                res->offsets.as<int64_t>() + c0, packed ? packedPairs : res->pairs.as<int2>(),
                                packed ? packedM1 : nullptr, packed ? packedM2 : nullptr, res->offsets.as<int64_t>() + c0,
                                packed ? reinterpret_cast<int64_t *>(packed) : nullptr);
