@@ -1371,7 +1371,8 @@ __global__ __launch_bounds__(SUM_THREADS) void ransac_sum_kernel(const RansacArg
     const bool live = hl < rows;
     const double *col = errBuf + (size_t)base * rows + (live ? hl : 0);
     const double none = __longlong_as_double(-1ll);
-    double bufA[PER], bufB[PER];
+    constexpr int DEPTH = 2; // tiles in flight (four measured the same: the additions, not the fetches, set the pace)
+    double bufs[DEPTH][PER];
     auto fetch = [&](double (&buf)[PER], int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
@@ -1379,39 +1380,56 @@ __global__ __launch_bounds__(SUM_THREADS) void ransac_sum_kernel(const RansacArg
             buf[i] = (live && k < n) ? col[(size_t)k * rows] : none;
         }
     };
-    int count = 0;
+    // Only the additions of a row depend on each other.  Telling inliers from the rest and counting them is
+    // done by the threads that fetch: a cell that is no inlier goes into the tile as -0.0 (x + (-0.0) = x for
+    // every x this sum can hold), so the chain is one LDS read and one addition per cell.
+    __shared__ int cnts[R];
+    if (tid < R) cnts[tid] = 0;
+    int cnt = 0;
     double tot = 0.0;
     auto consume = [&](double (&buf)[PER], int kNext) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < PER; i++) tile[sub + i * SLOTS][r] = buf[i];
+        for (int i = 0; i < PER; i++) { // cells past the end of the pair hold the "none" pattern
+            const bool in = buf[i] >= 0;
+            tile[sub + i * SLOTS][r] = in ? buf[i] : -0.0;
+            cnt += in ? 1 : 0;
+        }
         __syncthreads();
         if (kNext < n) fetch(buf, kNext);
-        if (tid < R) { // cells past the end of the pair hold the "none" pattern
+        if (tid < R) { // sixteen cells are on their way from LDS while the sixteen before them are added
+            double v[16], w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = tile[i][r];
 #pragma unroll 1
-            for (int kk = 0; kk < SUM_KT; kk += 16) {
-                double v[16];
+            for (int kk = 0; kk < SUM_KT; kk += 32) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = tile[kk + i][r];
+                for (int i = 0; i < 16; i++) w[i] = tile[kk + 16 + i][r];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const bool in = v[i] >= 0;
-                    // x + (-0.0) = x for every x this sum can hold, so the chain is one addition per cell
-                    tot = tot + (in ? v[i] : -0.0);
-                    count += in ? 1 : 0;
+                for (int i = 0; i < 16; i++) tot = tot + v[i];
+                if (kk + 32 < SUM_KT) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = tile[kk + 32 + i][r];
                 }
+#pragma unroll
+                for (int i = 0; i < 16; i++) tot = tot + w[i];
             }
         }
         __syncthreads();
     };
-    fetch(bufA, 0);
-    if (SUM_KT < n) fetch(bufB, SUM_KT);
-    for (int k0 = 0; k0 < n; k0 += 2 * SUM_KT) {
-        consume(bufA, k0 + 2 * SUM_KT);
-        if (k0 + SUM_KT < n) consume(bufB, k0 + 3 * SUM_KT);
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d * SUM_KT < n || d == 0) fetch(bufs[d], d * SUM_KT);
+    for (int k0 = 0; k0 < n; k0 += DEPTH * SUM_KT) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (k0 + d * SUM_KT < n) consume(bufs[d], k0 + (DEPTH + d) * SUM_KT);
     }
+    __syncthreads(); // (cnts is cleared also when the pair has no correspondences)
+    if (cnt) atomicAdd(&cnts[r], cnt);
+    __syncthreads();
     if (tid < R && live) {
         const int h = g.hBegin + hl;
-        g.counts[(size_t)p * g.H + h] = count;
+        g.counts[(size_t)p * g.H + h] = cnts[tid];
         g.toterr[(size_t)p * g.H + h] = tot;
     }
 }
