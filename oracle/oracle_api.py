@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
                                     C.c_double, C.c_double, C.c_int, C.c_int, _i32p,
                                     C.POINTER(C.c_int), _f64p, _i32p, _f64p, C.POINTER(C.c_int)]
     L.sfm_oracle_fit_hypotheses.argtypes = [_f64p, _f64p, _i32p, C.c_int, _f64p, _i32p]
+    L.sfm_oracle_fit_hypotheses_votes.argtypes = [_f64p, _f64p, _i32p, C.c_int, _f64p, _i32p, _i32p]
+    L.sfm_oracle_jacobi_svd_tall.argtypes = [_f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]
     L.sfm_oracle_normalize_points.argtypes = [_f64p, _f64p, C.c_int, _f64p]
     L.sfm_oracle_sample_table.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.c_int, _i32p]
     L.sfm_oracle_scale_chain.argtypes = [C.c_int, _i64p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int,
@@ -253,6 +255,30 @@ def fit_hypotheses(x, y, samples):
     cand = np.zeros(H, np.int32)
     lib().sfm_oracle_fit_hypotheses(x, y, samples, H, pose12.reshape(-1), cand)
     return pose12, cand
+
+
+def fit_hypotheses_votes(x, y, samples):
+    """fit_hypotheses plus the four cheirality counts of every row (eightPoint.cpp:299-337), candidate order
+    (R1,T), (R1,-T), (R2,T), (R2,-T)."""
+    x = np.ascontiguousarray(x, np.float64).reshape(-1, 2)
+    y = np.ascontiguousarray(y, np.float64).reshape(-1, 2)
+    samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 8)
+    H = samples.shape[0]
+    pose12 = np.zeros((H, 12))
+    cand = np.zeros(H, np.int32)
+    votes = np.zeros((H, 4), np.int32)
+    lib().sfm_oracle_fit_hypotheses_votes(x, y, samples, H, pose12.reshape(-1), cand, votes.reshape(-1))
+    return pose12, cand, votes
+
+
+def jacobi_svd_tall(A):
+    """The restated JacobiSVD(A, ComputeThinU | ComputeThinV) for a matrix with more rows than columns."""
+    A = np.ascontiguousarray(A, np.float64)
+    r, c = A.shape
+    assert r > c
+    U = np.zeros((r, c)); S = np.zeros(c); V = np.zeros((c, c))
+    lib().sfm_oracle_jacobi_svd_tall(A.reshape(-1), r, c, U.reshape(-1), S, V.reshape(-1))
+    return U, S, V
 
 
 def normalize_points(K, pixels):

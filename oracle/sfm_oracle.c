@@ -14,14 +14,16 @@
  *     (build with -ffp-contract=off, no -ffast-math);
  *   - the linear algebra that the reference delegates to Eigen >= 3.3 (a
  *     dependency absent from the reference tree and from this environment;
- *     CMakeLists.txt:27 pins no version): JacobiSVD of the 8x9 system and of
- *     the 3x3 essential matrix are replaced by the stated algorithms below
- *     (their results are unique up to the sign conventions the model cancels);
- *     colPivHouseholderQr().solve of the 3x2 triangulation system is restated
- *     from Eigen's published algorithm, operation by operation.  Tests
- *     cross-check all three against LAPACK (numpy.linalg.svd, SVD-based least
- *     squares) and count, over many seeds, the (hypothesis, correspondence)
- *     inlier decisions on which the restatement and LAPACK disagree.
+ *     CMakeLists.txt:27 pins no version) is restated from Eigen's published
+ *     algorithms, operation by operation: JacobiSVD of the 8x9 / n x 9 system
+ *     and of the 3x3 essential matrix (column-pivoted Householder QR as the
+ *     preconditioner, two-sided Jacobi sweeps, sign fix, descending sort), so
+ *     that signs and order -- which decide a tied cheirality vote -- are
+ *     Eigen's; and colPivHouseholderQr().solve of the 3x2 triangulation.
+ *     Tests cross-check all of them against LAPACK (numpy.linalg.svd,
+ *     SVD-based least squares) and count, over many seeds, the (hypothesis,
+ *     correspondence) inlier decisions on which the restatement and LAPACK
+ *     disagree.
  *
  * Reference files followed (paths relative to the reference tree):
  *   submodules/match/match.hpp:18-46     dotProduct, cosineSimilarity
@@ -35,6 +37,7 @@
  *
  * All matrices cross this API in Eigen's default layout: column-major.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -196,220 +199,411 @@ int sfm_oracle_match(const float *descA, const double *ptsA, int nA,
 }
 
 /* ------------------------------------------------------------------------ */
-/* Small dense linear algebra standing in for Eigen                          */
+/* Eigen's JacobiSVD, restated                                               */
 /* ------------------------------------------------------------------------ */
+/*
+ * The reference takes its null vector and the factors of the essential matrix from
+ * Eigen::JacobiSVD (eightPoint.cpp:85-86,93-96 and :254-255,262-265).  Which of the four (R, T)
+ * candidates comes first -- and so which one a tied cheirality vote keeps (:296-337) -- depends on
+ * the signs and the order that algorithm happens to return, so the algorithm itself is restated
+ * here from Eigen's published sources (Eigen 3.3 / 3.4, the versions CMakeLists.txt:27 admits;
+ * the two agree for real matrices): src/SVD/JacobiSVD.h (compute, qr_preconditioner_impl for
+ * ColPivHouseholderQRPreconditioner, the default), src/Jacobi/Jacobi.h (makeJacobi,
+ * apply_rotation_in_the_plane), src/misc/RealSvd2x2.h (real_2x2_jacobi_svd),
+ * src/QR/ColPivHouseholderQR.h (computeInPlace), src/Householder/Householder.h (makeHouseholder,
+ * applyHouseholderOnTheLeft) and HouseholderSequence.h (evalTo).
+ *
+ *   compute(A):  scale = max |A_ij| (1 when that is 0); everything below works on A / scale.
+ *     rows < cols (the 8x9 system of a sample): column-pivoted Householder QR of A^T (9x8);
+ *        V = its 9x9 Q; the Jacobi sweeps then rotate V's first 8 columns only, and the final
+ *        sort moves only those, so matrixV().col(8) is Q's last column, H_0 H_1 ... H_7 e_8,
+ *        formed by evalTo from the last reflector to the first.
+ *     rows > cols (a refit on more than nine points): column-pivoted Householder QR of A; the
+ *        work matrix is the upper triangle R (9x9), V starts as the column permutation.
+ *     rows == cols: the work matrix is A / scale, V starts as the identity.
+ *     sweeps: for p = 1..m-1, q = 0..p-1: when |W_pq| or |W_qp| exceeds
+ *        max(DBL_MIN, 2 eps max|diagonal entry seen so far|): real_2x2_jacobi_svd gives a left
+ *        and a right rotation; W <- J_left W, U <- U J_left^T, W <- W J_right, V <- V J_right;
+ *        repeated until a whole sweep finds nothing to do.
+ *     then S_i = |W_ii|, U's column i negated where W_ii < 0, S *= scale, and a selection sort
+ *        into descending order (the first of equal maxima), swapping the columns of U and V.
+ *
+ * PARITY UNPINNED at the level of single roundings: Eigen is absent here, so no output of Eigen
+ * pins this file.  What is restated is the sequence of operations; where Eigen leaves the order
+ * of a sum to its vectorised kernels (the squared norms and the reflector-times-block products
+ * of the QR) the sums below run top to bottom, and an Eigen built with fused multiply-adds
+ * would round differently again.  Such differences are of the size of a rounding error; they do
+ * not change a sign, a pivot or the order of singular values except where two of them agree to
+ * rounding.
+ */
+typedef struct {
+    double c, s;
+} jrot_t;
+
+/* Jacobi.h, JacobiRotation::makeJacobi(x, y, z): the rotation that diagonalises the symmetric
+ * 2x2 matrix [x y; y z]. */
+static void make_jacobi(double x, double y, double z, jrot_t *j)
+{
+    const double deno = 2.0 * fabs(y);
+    if (deno < DBL_MIN) {
+        j->c = 1.0;
+        j->s = 0.0;
+        return;
+    }
+    const double tau = (x - z) / deno;
+    const double w = sqrt(tau * tau + 1.0);
+    double t;
+    if (tau > 0.0)
+        t = 1.0 / (tau + w);
+    else
+        t = 1.0 / (tau - w);
+    const double sign_t = t > 0.0 ? 1.0 : -1.0;
+    const double n = 1.0 / sqrt(t * t + 1.0);
+    j->s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+    j->c = n;
+}
+
+/* RealSvd2x2.h, real_2x2_jacobi_svd on m = [m00 m01; m10 m11]: J_left m J_right is diagonal. */
+static void real_2x2_jacobi_svd(double m00, double m01, double m10, double m11, jrot_t *j_left, jrot_t *j_right)
+{
+    jrot_t rot1;
+    const double t = m00 + m11;
+    const double d = m10 - m01;
+    if (fabs(d) < DBL_MIN) {
+        rot1.s = 0.0;
+        rot1.c = 1.0;
+    } else {
+        const double u = t / d;
+        const double tmp = sqrt(1.0 + u * u);
+        rot1.s = 1.0 / tmp;
+        rot1.c = u / tmp;
+    }
+    /* m.applyOnTheLeft(0, 1, rot1); only m00, m01, m11 of the result are used */
+    double r00 = m00, r01 = m01, r11 = m11;
+    if (!(rot1.c == 1.0 && rot1.s == 0.0)) {
+        r00 = rot1.c * m00 + rot1.s * m10;
+        r01 = rot1.c * m01 + rot1.s * m11;
+        r11 = -rot1.s * m01 + rot1.c * m11;
+    }
+    make_jacobi(r00, r01, r11, j_right);
+    /* *j_left = rot1 * j_right->transpose() */
+    const double oc = j_right->c, os = -j_right->s;
+    j_left->c = rot1.c * oc - rot1.s * os;
+    j_left->s = rot1.c * os + rot1.s * oc;
+}
+
+/* Jacobi.h, apply_rotation_in_the_plane: (x_i, y_i) <- (c x_i + s y_i, -s x_i + c y_i). */
+static void rotate_plane(double *x, double *y, int n, int stride, double c, double s)
+{
+    if (c == 1.0 && s == 0.0)
+        return;
+    for (int i = 0; i < n; i++) {
+        const double xi = x[i * stride], yi = y[i * stride];
+        x[i * stride] = c * xi + s * yi;
+        y[i * stride] = -s * xi + c * yi;
+    }
+}
 
 /*
- * Null vector of an 8x9 matrix A (row-major a[8][9]): the unit vector q with
- * A q = 0.  Stands in for JacobiSVD(A, ComputeFullV).matrixV().col(8)
- * (eightPoint.cpp:254-255), which for a rank-8 A is that same vector up to
- * sign.  Method: Householder QR of B = A^T (9x8); q is the last column of Q.
- * Evaluation order is fixed (and mirrored by the GPU kernel): column norms
- * and inner products are accumulated top to bottom.
+ * JacobiSVD::compute from "step 2" on, for a square m x m work matrix W (row-major, already
+ * divided by scale): the sweeps, the sign fix and the sort.  U (urows x m, row-major) and V
+ * (vrows x m, row-major) accumulate the rotations from whatever they hold on entry; either may be
+ * NULL.  S receives the singular values, descending.
+ */
+static void jacobi_svd_square(int m, double *W, double *U, int urows, double *V, int vrows, double scale, double *S)
+{
+    const double precision = 2.0 * DBL_EPSILON;
+    const double considerAsZero = DBL_MIN;
+    double maxDiagEntry = 0.0;
+    for (int i = 0; i < m; i++)
+        if (fabs(W[i * m + i]) > maxDiagEntry)
+            maxDiagEntry = fabs(W[i * m + i]);
+    int finished = 0;
+    /* (Eigen has no sweep limit: a NaN fails every comparison and ends the loop at once; the cap
+     * only guards this restatement against an input Eigen would spin on.) */
+    for (int sweep = 0; !finished && sweep < 1000; sweep++) {
+        finished = 1;
+        for (int p = 1; p < m; p++) {
+            for (int q = 0; q < p; q++) {
+                const double pm = precision * maxDiagEntry;
+                const double threshold = (considerAsZero < pm) ? pm : considerAsZero;
+                if (fabs(W[p * m + q]) > threshold || fabs(W[q * m + p]) > threshold) {
+                    finished = 0;
+                    jrot_t jl, jr;
+                    real_2x2_jacobi_svd(W[p * m + p], W[p * m + q], W[q * m + p], W[q * m + q], &jl, &jr);
+                    rotate_plane(W + p * m, W + q * m, m, 1, jl.c, jl.s);   /* rows p, q */
+                    if (U)
+                        rotate_plane(U + p, U + q, urows, m, jl.c, jl.s);       /* columns p, q, by (J_left^T)^T */
+                    rotate_plane(W + p, W + q, m, m, jr.c, -jr.s);          /* columns p, q, by J_right^T */
+                    if (V)
+                        rotate_plane(V + p, V + q, vrows, m, jr.c, -jr.s);
+                    const double app = fabs(W[p * m + p]), aqq = fabs(W[q * m + q]);
+                    const double mx = (app < aqq) ? aqq : app;
+                    if (maxDiagEntry < mx)
+                        maxDiagEntry = mx;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < m; i++) {
+        const double a = W[i * m + i];
+        S[i] = fabs(a);
+        if (U && a < 0.0)
+            for (int r = 0; r < urows; r++)
+                U[r * m + i] = -U[r * m + i];
+    }
+    for (int i = 0; i < m; i++)
+        S[i] = S[i] * scale;
+    for (int i = 0; i < m; i++) {
+        int pos = 0;
+        double best = S[i];
+        for (int k = i + 1; k < m; k++)
+            if (S[k] > best) {
+                best = S[k];
+                pos = k - i;
+            }
+        if (best == 0.0)
+            break;
+        if (pos) {
+            pos += i;
+            double t = S[i];
+            S[i] = S[pos];
+            S[pos] = t;
+            if (U)
+                for (int r = 0; r < urows; r++) {
+                    t = U[r * m + i];
+                    U[r * m + i] = U[r * m + pos];
+                    U[r * m + pos] = t;
+                }
+            if (V)
+                for (int r = 0; r < vrows; r++) {
+                    t = V[r * m + i];
+                    V[r * m + i] = V[r * m + pos];
+                    V[r * m + pos] = t;
+                }
+        }
+    }
+}
+
+/* Householder.h, makeHouseholder on the vector v[0..len-1]: the tail becomes the essential part
+ * (in place), *beta the new leading coefficient, *tau the reflector's factor. */
+static void make_householder_in_place(double *v, int len, double *tau, double *beta)
+{
+    double tailSqNorm = 0.0;
+    for (int i = 1; i < len; i++)
+        tailSqNorm = tailSqNorm + v[i] * v[i];
+    const double c0 = v[0];
+    if (tailSqNorm <= DBL_MIN) {
+        *tau = 0.0;
+        *beta = c0;
+        for (int i = 1; i < len; i++)
+            v[i] = 0.0;
+    } else {
+        double b = sqrt(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0)
+            b = -b;
+        for (int i = 1; i < len; i++)
+            v[i] = v[i] / (c0 - b);
+        *tau = (b - c0) / b;
+        *beta = b;
+    }
+}
+
+/* Householder.h, applyHouseholderOnTheLeft on one column w[0..len-1] (essential has len-1 entries):
+ * tmp = essential . w[1:] + w[0]; w[0] -= tau tmp; w[1:] -= tmp (tau essential). */
+static void apply_householder_left(double *w, int len, const double *essential, double tau)
+{
+    if (len == 1) {
+        w[0] = w[0] * (1.0 - tau);
+        return;
+    }
+    if (tau == 0.0)
+        return;
+    double tmp = 0.0;
+    for (int i = 1; i < len; i++)
+        tmp = tmp + essential[i - 1] * w[i];
+    tmp = tmp + w[0];
+    w[0] = w[0] - tau * tmp;
+    for (int i = 1; i < len; i++)
+        w[i] = w[i] - tmp * (tau * essential[i - 1]);
+}
+
+static double column_norm(const double *v, int len)
+{
+    double s = 0.0;
+    for (int i = 0; i < len; i++)
+        s = s + v[i] * v[i];
+    return sqrt(s);
+}
+
+/*
+ * ColPivHouseholderQR.h, computeInPlace, on a rows x cols matrix stored by columns
+ * (M[c * rows + r]).  On return the upper triangle holds R, the columns below the diagonal the
+ * essential parts, hcoeffs the factors and transp[k] the column that step k swapped into place.
+ * The count of pivots above Eigen's threshold is returned (it decides nothing on this path).
+ */
+static int colpiv_householder_qr(double *M, int rows, int cols, double *hcoeffs, int *transp)
+{
+    const int size = rows < cols ? rows : cols;
+    double *normsUpdated = (double *)malloc(sizeof(double) * (size_t)cols * 2);
+    double *normsDirect = normsUpdated + cols;
+    double maxNorm = 0.0;
+    for (int k = 0; k < cols; k++) {
+        normsDirect[k] = column_norm(M + (size_t)k * rows, rows);
+        normsUpdated[k] = normsDirect[k];
+        if (k == 0 || normsUpdated[k] > maxNorm)
+            maxNorm = normsUpdated[k];
+    }
+    const double threshold_helper = ((maxNorm * DBL_EPSILON) * (maxNorm * DBL_EPSILON)) / (double)rows;
+    const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+    int nonzero_pivots = size;
+    for (int k = 0; k < size; k++) {
+        int biggest = k;
+        double bn = normsUpdated[k];
+        for (int j = k + 1; j < cols; j++)
+            if (normsUpdated[j] > bn) {
+                bn = normsUpdated[j];
+                biggest = j;
+            }
+        const double biggest_col_sq_norm = bn * bn;
+        if (nonzero_pivots == size && biggest_col_sq_norm < threshold_helper * (double)(rows - k))
+            nonzero_pivots = k;
+        transp[k] = biggest;
+        if (k != biggest) {
+            double *a = M + (size_t)k * rows, *b = M + (size_t)biggest * rows;
+            for (int r = 0; r < rows; r++) {
+                const double t = a[r];
+                a[r] = b[r];
+                b[r] = t;
+            }
+            double t = normsUpdated[k];
+            normsUpdated[k] = normsUpdated[biggest];
+            normsUpdated[biggest] = t;
+            t = normsDirect[k];
+            normsDirect[k] = normsDirect[biggest];
+            normsDirect[biggest] = t;
+        }
+        double beta;
+        double *colk = M + (size_t)k * rows + k;
+        make_householder_in_place(colk, rows - k, &hcoeffs[k], &beta);
+        colk[0] = beta;
+        for (int j = k + 1; j < cols; j++)
+            apply_householder_left(M + (size_t)j * rows + k, rows - k, colk + 1, hcoeffs[k]);
+        for (int j = k + 1; j < cols; j++) {
+            if (normsUpdated[j] != 0.0) {
+                double temp = fabs(M[(size_t)j * rows + k]) / normsUpdated[j];
+                temp = (1.0 + temp) * (1.0 - temp);
+                temp = temp < 0.0 ? 0.0 : temp;
+                const double ratio = normsUpdated[j] / normsDirect[j];
+                const double temp2 = temp * (ratio * ratio);
+                if (temp2 <= norm_downdate_threshold) {
+                    normsDirect[j] = column_norm(M + (size_t)j * rows + k + 1, rows - k - 1);
+                    normsUpdated[j] = normsDirect[j];
+                } else {
+                    normsUpdated[j] = normsUpdated[j] * sqrt(temp);
+                }
+            }
+        }
+    }
+    free(normsUpdated);
+    return nonzero_pivots;
+}
+
+/*
+ * JacobiSVD(A, ComputeFullV).matrixV().col(8) for the 8x9 system of a sample (a[8][9], row-major;
+ * eightPoint.cpp:254-255): the last column of the Q of the pivoted QR of (A / scale)^T.
  */
 static void null_vector_8x9(const double a[8][9], double q[9])
 {
-    double B[9][8];
-    for (int r = 0; r < 9; r++)
-        for (int c = 0; c < 8; c++)
-            B[r][c] = a[c][r];
-
-    double tau[8]; /* 2 / (v.v), or 0 when the reflection is skipped */
-    for (int j = 0; j < 8; j++) {
-        double sigma = 0.0;
-        for (int r = j; r < 9; r++)
-            sigma = sigma + B[r][j] * B[r][j];
-        double nrm = sqrt(sigma);
-        if (nrm == 0.0) {
-            tau[j] = 0.0;
-            continue;
-        }
-        double alpha = (B[j][j] > 0.0) ? -nrm : nrm;
-        /* v = x - alpha e1, stored in place of x */
-        B[j][j] = B[j][j] - alpha;
-        double vv = 0.0;
-        for (int r = j; r < 9; r++)
-            vv = vv + B[r][j] * B[r][j];
-        tau[j] = 2.0 / vv;
-        for (int c = j + 1; c < 8; c++) {
-            double s = 0.0;
-            for (int r = j; r < 9; r++)
-                s = s + B[r][j] * B[r][c];
-            s = s * tau[j];
-            for (int r = j; r < 9; r++)
-                B[r][c] = B[r][c] - s * B[r][j];
-        }
-    }
-
+    double scale = 0.0;
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 9; c++)
+            if (fabs(a[r][c]) > scale)
+                scale = fabs(a[r][c]);
+    if (scale == 0.0)
+        scale = 1.0;
+    double M[8 * 9]; /* column c of A^T is row c of A */
+    for (int c = 0; c < 8; c++)
+        for (int r = 0; r < 9; r++)
+            M[c * 9 + r] = a[c][r] / scale;
+    double h[8];
+    int transp[8];
+    colpiv_householder_qr(M, 9, 8, h, transp);
+    /* HouseholderSequence::evalTo, the column it makes of e_8 */
     for (int r = 0; r < 9; r++)
         q[r] = 0.0;
     q[8] = 1.0;
-    for (int j = 7; j >= 0; j--) {
-        if (tau[j] == 0.0)
-            continue;
-        double s = 0.0;
-        for (int r = j; r < 9; r++)
-            s = s + B[r][j] * q[r];
-        s = s * tau[j];
-        for (int r = j; r < 9; r++)
-            q[r] = q[r] - s * B[r][j];
-    }
-    /* Q is orthogonal, so q is unit up to rounding; renormalise like an SVD
-     * would return it. */
-    double n2 = 0.0;
-    for (int r = 0; r < 9; r++)
-        n2 = n2 + q[r] * q[r];
-    double inv = 1.0 / sqrt(n2);
-    for (int r = 0; r < 9; r++)
-        q[r] = q[r] * inv;
+    for (int k = 7; k >= 0; k--)
+        apply_householder_left(q + k, 9 - k, M + k * 9 + k + 1, h[k]);
 }
 
 /*
- * Right singular vector of the smallest singular value of an n x 9 matrix
- * (row-major), n >= 9: one-sided (Hestenes) Jacobi on the columns.  Stands in
- * for JacobiSVD(A, ComputeFullV).matrixV().col(8) in the refit overload
- * (eightPoint.cpp:85-86).
+ * JacobiSVD(A, ComputeFullV).matrixV().col(8) for an n x 9 system, n >= 9 (row-major a; the
+ * refit, eightPoint.cpp:85-86).
  */
 static void smallest_right_singular_vector_nx9(const double *a, int n, double q[9])
 {
-    double *G = (double *)malloc((size_t)n * 9 * sizeof(double));
-    double V[9][9];
-    memcpy(G, a, (size_t)n * 9 * sizeof(double));
-    for (int i = 0; i < 9; i++)
-        for (int j = 0; j < 9; j++)
-            V[i][j] = (i == j) ? 1.0 : 0.0;
-
-    for (int sweep = 0; sweep < 60; sweep++) {
-        int rotated = 0;
-        for (int p = 0; p < 8; p++) {
-            for (int qc = p + 1; qc < 9; qc++) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int i = 0; i < n; i++) {
-                    double gp = G[i * 9 + p], gq = G[i * 9 + qc];
-                    alpha += gp * gp;
-                    beta += gq * gq;
-                    gamma += gp * gq;
-                }
-                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))
-                    continue;
-                rotated = 1;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t);
-                double s = c * t;
-                for (int i = 0; i < n; i++) {
-                    double gp = G[i * 9 + p], gq = G[i * 9 + qc];
-                    G[i * 9 + p] = c * gp - s * gq;
-                    G[i * 9 + qc] = s * gp + c * gq;
-                }
-                for (int i = 0; i < 9; i++) {
-                    double vp = V[i][p], vq = V[i][qc];
-                    V[i][p] = c * vp - s * vq;
-                    V[i][qc] = s * vp + c * vq;
-                }
-            }
+    double scale = 0.0;
+    for (size_t i = 0; i < (size_t)n * 9; i++)
+        if (fabs(a[i]) > scale)
+            scale = fabs(a[i]);
+    if (scale == 0.0)
+        scale = 1.0;
+    double W[81], V[81], S[9];
+    if (n == 9) {
+        for (int i = 0; i < 81; i++) {
+            W[i] = a[i] / scale;
+            V[i] = (i / 9 == i % 9) ? 1.0 : 0.0;
         }
-        if (!rotated)
-            break;
-    }
-    int best = 0;
-    double bestn = INFINITY;
-    for (int j = 0; j < 9; j++) {
-        double nn = 0;
-        for (int i = 0; i < n; i++)
-            nn += G[i * 9 + j] * G[i * 9 + j];
-        if (nn < bestn) {
-            bestn = nn;
-            best = j;
+    } else {
+        double *M = (double *)malloc(sizeof(double) * (size_t)n * 9);
+        for (int c = 0; c < 9; c++)
+            for (int r = 0; r < n; r++)
+                M[(size_t)c * n + r] = a[(size_t)r * 9 + c] / scale;
+        double h[9];
+        int transp[9], perm[9];
+        colpiv_householder_qr(M, n, 9, h, transp);
+        for (int i = 0; i < 9; i++)
+            for (int j = 0; j < 9; j++)
+                W[i * 9 + j] = (i <= j) ? M[(size_t)j * n + i] : 0.0;
+        /* colsPermutation(): the transpositions applied on the right of the identity */
+        for (int i = 0; i < 9; i++)
+            perm[i] = i;
+        for (int k = 0; k < 9; k++) {
+            const int t = perm[k];
+            perm[k] = perm[transp[k]];
+            perm[transp[k]] = t;
         }
+        for (int i = 0; i < 9; i++)
+            for (int j = 0; j < 9; j++)
+                V[i * 9 + j] = (i == perm[j]) ? 1.0 : 0.0;
+        free(M);
     }
+    jacobi_svd_square(9, W, NULL, 0, V, 9, scale, S);
     for (int i = 0; i < 9; i++)
-        q[i] = V[i][best];
-    free(G);
+        q[i] = V[i * 9 + 8];
 }
 
 /*
- * SVD of a 3x3 matrix E (row-major e[3][3]) = U diag(S) V^T with S sorted
- * descending.  Stands in for JacobiSVD<Mat3>(E, FullU|FullV)
- * (eightPoint.cpp:262-265).  One-sided Jacobi on the columns of G = E;
- * a column whose norm vanishes against S[0] is replaced by the cross product
- * of the other two so that U stays orthogonal.
+ * JacobiSVD<Mat3>(E, ComputeFullU | ComputeFullV) (eightPoint.cpp:93-96, :262-265): E (row-major)
+ * = U diag(S) V^T, S descending.
  */
 static void svd3(const double e[3][3], double U[3][3], double S[3], double V[3][3])
 {
-    double G[3][3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
-            G[i][j] = e[i][j];
-            V[i][j] = (i == j) ? 1.0 : 0.0;
-        }
-    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-    for (int sweep = 0; sweep < 30; sweep++) {
-        int rotated = 0;
-        for (int k = 0; k < 3; k++) {
-            const int p = PQ[k][0], q = PQ[k][1];
-            double alpha = (G[0][p] * G[0][p] + G[1][p] * G[1][p]) + G[2][p] * G[2][p];
-            double beta = (G[0][q] * G[0][q] + G[1][q] * G[1][q]) + G[2][q] * G[2][q];
-            double gamma = (G[0][p] * G[0][q] + G[1][p] * G[1][q]) + G[2][p] * G[2][q];
-            if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))
-                continue;
-            rotated = 1;
-            double zeta = (beta - alpha) / (2.0 * gamma);
-            double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            double c = 1.0 / sqrt(1.0 + t * t);
-            double s = c * t;
-            for (int i = 0; i < 3; i++) {
-                double gp = G[i][p], gq = G[i][q];
-                G[i][p] = c * gp - s * gq;
-                G[i][q] = s * gp + c * gq;
-                double vp = V[i][p], vq = V[i][q];
-                V[i][p] = c * vp - s * vq;
-                V[i][q] = s * vp + c * vq;
-            }
-        }
-        if (!rotated)
-            break;
-    }
-    double nrm[3];
-    for (int j = 0; j < 3; j++)
-        nrm[j] = sqrt((G[0][j] * G[0][j] + G[1][j] * G[1][j]) + G[2][j] * G[2][j]);
-    /* stable descending order of three values */
-    int ord[3] = {0, 1, 2};
-    if (nrm[ord[1]] > nrm[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
-    if (nrm[ord[2]] > nrm[ord[1]]) { int t = ord[1]; ord[1] = ord[2]; ord[2] = t; }
-    if (nrm[ord[1]] > nrm[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
-    double Vs[3][3];
-    for (int j = 0; j < 3; j++) {
-        const int src = ord[j];
-        S[j] = nrm[src];
-        for (int i = 0; i < 3; i++) {
-            Vs[i][j] = V[i][src];
-            U[i][j] = (nrm[src] > 0.0) ? G[i][src] / nrm[src] : 0.0;
-        }
-    }
+    double scale = 0.0;
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
-            V[i][j] = Vs[i][j];
-    /* complete U when trailing singular values vanish */
-    const double tiny = 1e-12 * S[0];
-    if (S[0] > 0.0 && S[1] <= tiny) {
-        /* rank <= 1: any unit vector orthogonal to u0 */
-        int m = 0;
-        if (fabs(U[1][0]) < fabs(U[m][0])) m = 1;
-        if (fabs(U[2][0]) < fabs(U[m][0])) m = 2;
-        double ax[3] = {0, 0, 0};
-        ax[m] = 1.0;
-        double c0 = U[1][0] * ax[2] - U[2][0] * ax[1];
-        double c1 = U[2][0] * ax[0] - U[0][0] * ax[2];
-        double c2 = U[0][0] * ax[1] - U[1][0] * ax[0];
-        double cn = sqrt((c0 * c0 + c1 * c1) + c2 * c2);
-        U[0][1] = c0 / cn; U[1][1] = c1 / cn; U[2][1] = c2 / cn;
-    }
-    if (S[0] > 0.0 && S[2] <= tiny) {
-        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
-        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
-        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
-    }
+            if (fabs(e[i][j]) > scale)
+                scale = fabs(e[i][j]);
+    if (scale == 0.0)
+        scale = 1.0;
+    double W[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            W[i * 3 + j] = e[i][j] / scale;
+            U[i][j] = V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    jacobi_svd_square(3, W, &U[0][0], 3, &V[0][0], 3, scale, S);
 }
 
 /*
@@ -828,6 +1022,55 @@ void sfm_oracle_null_vector(const double *a_rowmajor, int n, double *q9)
     }
 }
 
+/*
+ * JacobiSVD<MatrixXd>(A, ComputeThinU | ComputeThinV) for rows > cols (a row-major): thin U
+ * (rows x cols), S, V (cols x cols), row-major.  Not on the reference's path with these options;
+ * it runs the same restated pieces (pivoted QR, householderQ applied to the identity, the sweeps,
+ * the sign fix, the sort) and exists so that a test can compare them with the one output of
+ * Eigen's JacobiSVD that is widely published: the example in its class documentation.
+ */
+void sfm_oracle_jacobi_svd_tall(const double *a, int rows, int cols, double *U, double *S, double *V)
+{
+    double scale = 0.0;
+    for (size_t i = 0; i < (size_t)rows * cols; i++)
+        if (fabs(a[i]) > scale)
+            scale = fabs(a[i]);
+    if (scale == 0.0)
+        scale = 1.0;
+    double *M = (double *)malloc(sizeof(double) * ((size_t)rows * cols + (size_t)cols * cols + cols + rows));
+    double *W = M + (size_t)rows * cols, *h = W + (size_t)cols * cols, *col = h + cols;
+    int *transp = (int *)malloc(sizeof(int) * 2 * (size_t)cols), *perm = transp + cols;
+    for (int c = 0; c < cols; c++)
+        for (int r = 0; r < rows; r++)
+            M[(size_t)c * rows + r] = a[(size_t)r * cols + c] / scale;
+    colpiv_householder_qr(M, rows, cols, h, transp);
+    for (int i = 0; i < cols; i++)
+        for (int j = 0; j < cols; j++)
+            W[i * cols + j] = (i <= j) ? M[(size_t)j * rows + i] : 0.0;
+    /* thin U: householderQ() applied to the first cols columns of the identity, last reflector first */
+    for (int j = 0; j < cols; j++) {
+        for (int r = 0; r < rows; r++)
+            col[r] = (r == j) ? 1.0 : 0.0;
+        for (int k = cols - 1; k >= 0; k--)
+            apply_householder_left(col + k, rows - k, M + (size_t)k * rows + k + 1, h[k]);
+        for (int r = 0; r < rows; r++)
+            U[(size_t)r * cols + j] = col[r];
+    }
+    for (int i = 0; i < cols; i++)
+        perm[i] = i;
+    for (int k = 0; k < cols; k++) {
+        const int t = perm[k];
+        perm[k] = perm[transp[k]];
+        perm[transp[k]] = t;
+    }
+    for (int i = 0; i < cols; i++)
+        for (int j = 0; j < cols; j++)
+            V[i * cols + j] = (i == perm[j]) ? 1.0 : 0.0;
+    jacobi_svd_square(cols, W, U, rows, V, cols, scale, S);
+    free(M);
+    free(transp);
+}
+
 void sfm_oracle_triangulate(const double *a, const double *b, const double *T, double *lambdas2)
 {
     double bb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
@@ -1069,8 +1312,9 @@ int sfm_oracle_ransac(const double *x, const double *y, int n, const double *K, 
 }
 
 /* Per-hypothesis poses for a sample table: pose12[h] = R row-major (9) then T (3). */
-void sfm_oracle_fit_hypotheses(const double *x, const double *y, const int *samples, int H,
-                               double *pose12_out, int *candidate_out)
+/* votes_out (may be NULL): the four cheirality counts of every row, in candidate order. */
+void sfm_oracle_fit_hypotheses_votes(const double *x, const double *y, const int *samples, int H,
+                                     double *pose12_out, int *candidate_out, int *votes_out)
 {
 #pragma omp parallel for schedule(static)
     for (int h = 0; h < H; h++) {
@@ -1082,7 +1326,7 @@ void sfm_oracle_fit_hypotheses(const double *x, const double *y, const int *samp
             cy[2 * k] = y[2 * s[k]];
             cy[2 * k + 1] = y[2 * s[k] + 1];
         }
-        int c = fit_pose(cx, cy, 8, R, T, NULL);
+        int c = fit_pose(cx, cy, 8, R, T, votes_out ? votes_out + (size_t)h * 4 : NULL);
         double *o = pose12_out + (size_t)h * 12;
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++)
@@ -1092,6 +1336,12 @@ void sfm_oracle_fit_hypotheses(const double *x, const double *y, const int *samp
         if (candidate_out)
             candidate_out[h] = c;
     }
+}
+
+void sfm_oracle_fit_hypotheses(const double *x, const double *y, const int *samples, int H,
+                               double *pose12_out, int *candidate_out)
+{
+    sfm_oracle_fit_hypotheses_votes(x, y, samples, H, pose12_out, candidate_out, NULL);
 }
 
 /* scene.cpp:495-501: (K^-1 [u, v, 1])_{0,1}; Kinv column-major. */

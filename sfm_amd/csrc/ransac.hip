@@ -16,9 +16,9 @@
 //
 // All fp64 arithmetic below is written operation by operation (this file is compiled with
 // contraction off): same products, same sums, same order as the CPU restatement the tests
-// compare against, so counts and error sums agree bit for bit.  Eigen's JacobiSVD and
-// JacobiSVD is replaced by Householder QR of A^T for the null vector and one-sided Jacobi for the 3x3
-// SVD; colPivHouseholderQr().solve of the 3x2 triangulation system is followed operation by operation.
+// compare against, so counts and error sums agree bit for bit.  Eigen's JacobiSVD (the 8x9 system's null
+// vector, the 3x3 essential matrix) and colPivHouseholderQr().solve (the 3x2 triangulation system) are
+// followed operation by operation, so that signs, pivots and the order of the candidates are Eigen's.
 #include "common.h"
 
 #include <cmath>
@@ -351,148 +351,292 @@ __device__ __forceinline__ double det3(const double M[3][3])
            M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
 }
 
-// Unit null vector of the 8x9 matrix whose transpose is B (9x8): Householder QR of B, last
-// column of Q.  Every loop is unrolled so that B lives in registers.
-__device__ __forceinline__ void null_vector_8x9(double B[9][8], double q[9])
+// Eigen's JacobiSVD, which the reference takes its null vector and the factors of the essential matrix from
+// (eightPoint.cpp:254-255, :262-265), written out: the order of the four (R, T) candidates, and with it the
+// outcome of a tied cheirality vote (:296-337), depends on the signs and the order that algorithm returns.
+// Sources followed (Eigen 3.3 / 3.4): JacobiSVD::compute and its ColPivHouseholderQR preconditioner,
+// ColPivHouseholderQR::computeInPlace, makeHouseholder, applyHouseholderOnTheLeft, HouseholderSequence::evalTo,
+// real_2x2_jacobi_svd, JacobiRotation::makeJacobi, apply_rotation_in_the_plane.  Sums run in index order, as in
+// the CPU restatement the tests compare with bit for bit.
+#define SFM_DBL_MIN 2.2250738585072014e-308
+#define SFM_DBL_EPS 2.220446049250313e-16
+
+struct JRot {
+    double c, s;
+};
+
+// JacobiRotation::makeJacobi(x, y, z): diagonalises [x y; y z].
+__device__ __forceinline__ void make_jacobi(double x, double y, double z, JRot &j)
 {
-    double tau[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        double sigma = 0.0;
-#pragma unroll
-        for (int r = j; r < 9; r++) sigma = sigma + B[r][j] * B[r][j];
-        const double nrm = sqrt(sigma);
-        if (nrm == 0.0) {
-            tau[j] = 0.0;
-        } else {
-            const double alpha = (B[j][j] > 0.0) ? -nrm : nrm;
-            B[j][j] = B[j][j] - alpha;
-            double vv = 0.0;
-#pragma unroll
-            for (int r = j; r < 9; r++) vv = vv + B[r][j] * B[r][j];
-            tau[j] = 2.0 / vv;
-#pragma unroll
-            for (int c = j + 1; c < 8; c++) {
-                double s = 0.0;
-#pragma unroll
-                for (int r = j; r < 9; r++) s = s + B[r][j] * B[r][c];
-                s = s * tau[j];
-#pragma unroll
-                for (int r = j; r < 9; r++) B[r][c] = B[r][c] - s * B[r][j];
-            }
-        }
+    const double deno = 2.0 * fabs(y);
+    if (deno < SFM_DBL_MIN) {
+        j.c = 1.0;
+        j.s = 0.0;
+        return;
     }
-#pragma unroll
-    for (int r = 0; r < 9; r++) q[r] = 0.0;
-    q[8] = 1.0;
-#pragma unroll
-    for (int j = 7; j >= 0; j--) {
-        if (tau[j] != 0.0) {
-            double s = 0.0;
-#pragma unroll
-            for (int r = j; r < 9; r++) s = s + B[r][j] * q[r];
-            s = s * tau[j];
-#pragma unroll
-            for (int r = j; r < 9; r++) q[r] = q[r] - s * B[r][j];
-        }
-    }
-    double n2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 9; r++) n2 = n2 + q[r] * q[r];
-    const double inv = 1.0 / sqrt(n2);
-#pragma unroll
-    for (int r = 0; r < 9; r++) q[r] = q[r] * inv;
+    const double tau = (x - z) / deno;
+    const double w = sqrt(tau * tau + 1.0);
+    const double t = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+    const double sign_t = t > 0.0 ? 1.0 : -1.0;
+    const double n = 1.0 / sqrt(t * t + 1.0);
+    j.s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+    j.c = n;
 }
 
-template <int P_, int Q_>
-__device__ __forceinline__ bool jacobi_rotate(double G[3][3], double V[3][3])
+// real_2x2_jacobi_svd on [m00 m01; m10 m11]: J_left m J_right is diagonal.
+__device__ __forceinline__ void real_2x2_jacobi_svd(double m00, double m01, double m10, double m11, JRot &jl, JRot &jr)
 {
-    const double alpha = (G[0][P_] * G[0][P_] + G[1][P_] * G[1][P_]) + G[2][P_] * G[2][P_];
-    const double beta = (G[0][Q_] * G[0][Q_] + G[1][Q_] * G[1][Q_]) + G[2][Q_] * G[2][Q_];
-    const double gamma = (G[0][P_] * G[0][Q_] + G[1][P_] * G[1][Q_]) + G[2][P_] * G[2][Q_];
-    if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) return false;
-    const double zeta = (beta - alpha) / (2.0 * gamma);
-    const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    const double c = 1.0 / sqrt(1.0 + t * t);
-    const double s = c * t;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const double gp = G[i][P_], gq = G[i][Q_];
-        G[i][P_] = c * gp - s * gq;
-        G[i][Q_] = s * gp + c * gq;
-        const double vp = V[i][P_], vq = V[i][Q_];
-        V[i][P_] = c * vp - s * vq;
-        V[i][Q_] = s * vp + c * vq;
+    JRot rot1;
+    const double t = m00 + m11;
+    const double d = m10 - m01;
+    if (fabs(d) < SFM_DBL_MIN) {
+        rot1.s = 0.0;
+        rot1.c = 1.0;
+    } else {
+        const double u = t / d;
+        const double tmp = sqrt(1.0 + u * u);
+        rot1.s = 1.0 / tmp;
+        rot1.c = u / tmp;
     }
+    const bool ident = rot1.c == 1.0 && rot1.s == 0.0;
+    const double r00 = ident ? m00 : rot1.c * m00 + rot1.s * m10;
+    const double r01 = ident ? m01 : rot1.c * m01 + rot1.s * m11;
+    const double r11 = ident ? m11 : -rot1.s * m01 + rot1.c * m11;
+    make_jacobi(r00, r01, r11, jr);
+    const double oc = jr.c, os = -jr.s; // j_left = rot1 * j_right.transpose()
+    jl.c = rot1.c * oc - rot1.s * os;
+    jl.s = rot1.c * os + rot1.s * oc;
+}
+
+// apply_rotation_in_the_plane on one (x, y): (c x + s y, -s x + c y); the identity leaves them untouched.
+__device__ __forceinline__ void rotate_pair(double &x, double &y, double c, double s, bool ident)
+{
+    const double xi = x, yi = y;
+    const double nx = c * xi + s * yi;
+    const double ny = -s * xi + c * yi;
+    x = ident ? xi : nx;
+    y = ident ? yi : ny;
+}
+
+// One (p, q) visit of a sweep of JacobiSVD<Mat3>: W <- J_left W, U <- U J_left^T, W <- W J_right, V <- V J_right.
+template <int P_, int Q_>
+__device__ __forceinline__ bool svd3_visit(double W[3][3], double U[3][3], double V[3][3], double &maxDiag)
+{
+    const double pm = (2.0 * SFM_DBL_EPS) * maxDiag;
+    const double threshold = (SFM_DBL_MIN < pm) ? pm : SFM_DBL_MIN;
+    if (!(fabs(W[P_][Q_]) > threshold || fabs(W[Q_][P_]) > threshold)) return false;
+    JRot jl, jr;
+    real_2x2_jacobi_svd(W[P_][P_], W[P_][Q_], W[Q_][P_], W[Q_][Q_], jl, jr);
+    const bool il = jl.c == 1.0 && jl.s == 0.0, ir = jr.c == 1.0 && -jr.s == 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) rotate_pair(W[P_][i], W[Q_][i], jl.c, jl.s, il);
+#pragma unroll
+    for (int i = 0; i < 3; i++) rotate_pair(U[i][P_], U[i][Q_], jl.c, jl.s, il);
+#pragma unroll
+    for (int i = 0; i < 3; i++) rotate_pair(W[i][P_], W[i][Q_], jr.c, -jr.s, ir);
+#pragma unroll
+    for (int i = 0; i < 3; i++) rotate_pair(V[i][P_], V[i][Q_], jr.c, -jr.s, ir);
+    const double app = fabs(W[P_][P_]), aqq = fabs(W[Q_][Q_]);
+    const double mx = (app < aqq) ? aqq : app;
+    if (maxDiag < mx) maxDiag = mx;
     return true;
 }
 
-__device__ __forceinline__ void swap_cols(double G[3][3], double V[3][3], double n[3], int a, int b)
+__device__ __forceinline__ void svd3_swap_cols(double U[3][3], double S[3], double V[3][3], int a, int b)
 {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double t = G[i][a];
-        G[i][a] = G[i][b];
-        G[i][b] = t;
+        double t = U[i][a];
+        U[i][a] = U[i][b];
+        U[i][b] = t;
         t = V[i][a];
         V[i][a] = V[i][b];
         V[i][b] = t;
     }
-    const double t = n[a];
-    n[a] = n[b];
-    n[b] = t;
+    const double t = S[a];
+    S[a] = S[b];
+    S[b] = t;
 }
 
-// E = U diag(S) V^T, S descending; one-sided Jacobi on the columns of E.
+// JacobiSVD<Mat3>(E, ComputeFullU | ComputeFullV): E = U diag(S) V^T, S descending.
 __device__ __forceinline__ void svd3(const double E[3][3], double U[3][3], double S[3], double V[3][3])
 {
-    double G[3][3];
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (fabs(E[i][j]) > scale) scale = fabs(E[i][j]);
+    if (scale == 0.0) scale = 1.0;
+    double W[3][3];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            G[i][j] = E[i][j];
-            V[i][j] = (i == j) ? 1.0 : 0.0;
+            W[i][j] = E[i][j] / scale;
+            U[i][j] = V[i][j] = (i == j) ? 1.0 : 0.0;
         }
-    for (int sweep = 0; sweep < 30; sweep++) {
-        bool rotated = jacobi_rotate<0, 1>(G, V);
-        rotated |= jacobi_rotate<0, 2>(G, V);
-        rotated |= jacobi_rotate<1, 2>(G, V);
-        if (!rotated) break;
+    double maxDiag = fabs(W[0][0]);
+    if (fabs(W[1][1]) > maxDiag) maxDiag = fabs(W[1][1]);
+    if (fabs(W[2][2]) > maxDiag) maxDiag = fabs(W[2][2]);
+    for (int sweep = 0; sweep < 1000; sweep++) {
+        bool any = svd3_visit<1, 0>(W, U, V, maxDiag);
+        any |= svd3_visit<2, 0>(W, U, V, maxDiag);
+        any |= svd3_visit<2, 1>(W, U, V, maxDiag);
+        if (!any) break;
     }
-    double nrm[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) nrm[j] = sqrt((G[0][j] * G[0][j] + G[1][j] * G[1][j]) + G[2][j] * G[2][j]);
-    // stable descending order of three values
-    if (nrm[1] > nrm[0]) swap_cols(G, V, nrm, 0, 1);
-    if (nrm[2] > nrm[1]) swap_cols(G, V, nrm, 1, 2);
-    if (nrm[1] > nrm[0]) swap_cols(G, V, nrm, 0, 1);
+    for (int i = 0; i < 3; i++) {
+        const double a = W[i][i];
+        S[i] = fabs(a);
+        if (a < 0.0) {
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        S[j] = nrm[j];
+            for (int r = 0; r < 3; r++) U[r][i] = -U[r][i];
+        }
+    }
 #pragma unroll
-        for (int i = 0; i < 3; i++) U[i][j] = (nrm[j] > 0.0) ? G[i][j] / nrm[j] : 0.0;
+    for (int i = 0; i < 3; i++) S[i] = S[i] * scale;
+    // selection sort, the first of equal maxima
+    {
+        int pos = 0;
+        double best = S[0];
+        if (S[1] > best) { best = S[1]; pos = 1; }
+        if (S[2] > best) { pos = 2; }
+        if (pos == 1) svd3_swap_cols(U, S, V, 0, 1);
+        if (pos == 2) svd3_swap_cols(U, S, V, 0, 2);
+        if (S[2] > S[1]) svd3_swap_cols(U, S, V, 1, 2);
     }
-    const double tiny = 1e-12 * S[0];
-    if (S[0] > 0.0 && S[1] <= tiny) {
-        // rank <= 1: a unit vector orthogonal to u0, built from the axis u0 is least aligned with
-        int m = 0;
-        if (fabs(U[1][0]) < fabs(U[m][0])) m = 1;
-        if (fabs(U[2][0]) < fabs((m == 0) ? U[0][0] : U[1][0])) m = 2;
-        const double ax0 = (m == 0) ? 1.0 : 0.0, ax1 = (m == 1) ? 1.0 : 0.0, ax2 = (m == 2) ? 1.0 : 0.0;
-        const double c0 = U[1][0] * ax2 - U[2][0] * ax1;
-        const double c1 = U[2][0] * ax0 - U[0][0] * ax2;
-        const double c2 = U[0][0] * ax1 - U[1][0] * ax0;
-        const double cn = sqrt((c0 * c0 + c1 * c1) + c2 * c2);
-        U[0][1] = c0 / cn;
-        U[1][1] = c1 / cn;
-        U[2][1] = c2 / cn;
+}
+
+// applyHouseholderOnTheLeft on one column w[K_..8] of a matrix with nine rows: tmp = essential . w[K_+1..] +
+// w[K_]; w[K_] -= tau tmp; w[K_+1..] -= tmp (tau essential).  The essential part is ess[K_+1..8].
+template <int K_>
+__device__ __forceinline__ void householder_apply9(double w[9], const double ess[9], double tau)
+{
+    if (tau != 0.0) {
+        double tmp = 0.0;
+#pragma unroll
+        for (int i = K_ + 1; i < 9; i++) tmp = tmp + ess[i] * w[i];
+        tmp = tmp + w[K_];
+        w[K_] = w[K_] - tau * tmp;
+#pragma unroll
+        for (int i = K_ + 1; i < 9; i++) w[i] = w[i] - tmp * (tau * ess[i]);
     }
-    if (S[0] > 0.0 && S[2] <= tiny) {
-        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
-        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
-        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+}
+
+// One step of ColPivHouseholderQR::computeInPlace on the 9x8 matrix whose column c is M[c][0..8].
+template <int K_>
+__device__ __forceinline__ void colpiv_step9x8(double M[8][9], double nu[8], double nd[8], double h[8])
+{
+    // the column of the largest updated norm, the first of equals, comes to position K_
+    int biggest = K_;
+    double bn = nu[K_];
+#pragma unroll
+    for (int j = K_ + 1; j < 8; j++)
+        if (nu[j] > bn) {
+            bn = nu[j];
+            biggest = j;
+        }
+#pragma unroll
+    for (int j = K_ + 1; j < 8; j++) {
+        const bool sw = biggest == j;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const double a = M[K_][r], b = M[j][r];
+            M[K_][r] = sw ? b : a;
+            M[j][r] = sw ? a : b;
+        }
+        const double u0 = nu[K_], u1 = nu[j], d0 = nd[K_], d1 = nd[j];
+        nu[K_] = sw ? u1 : u0;
+        nu[j] = sw ? u0 : u1;
+        nd[K_] = sw ? d1 : d0;
+        nd[j] = sw ? d0 : d1;
     }
+    // makeHouseholderInPlace on M[K_][K_..8]
+    double tailSqNorm = 0.0;
+#pragma unroll
+    for (int i = K_ + 1; i < 9; i++) tailSqNorm = tailSqNorm + M[K_][i] * M[K_][i];
+    const double c0 = M[K_][K_];
+    if (tailSqNorm <= SFM_DBL_MIN) {
+        h[K_] = 0.0;
+#pragma unroll
+        for (int i = K_ + 1; i < 9; i++) M[K_][i] = 0.0;
+    } else {
+        double b = sqrt(c0 * c0 + tailSqNorm);
+        if (c0 >= 0.0) b = -b;
+        const double den = c0 - b;
+#pragma unroll
+        for (int i = K_ + 1; i < 9; i++) M[K_][i] = M[K_][i] / den;
+        h[K_] = (b - c0) / b;
+        M[K_][K_] = b;
+    }
+#pragma unroll
+    for (int j = K_ + 1; j < 8; j++) householder_apply9<K_>(M[j], M[K_], h[K_]);
+    // the norms of the remaining columns, downdated as in LAPACK's xGEQPF
+#pragma unroll
+    for (int j = K_ + 1; j < 8; j++) {
+        if (nu[j] != 0.0) {
+            double temp = fabs(M[j][K_]) / nu[j];
+            temp = (1.0 + temp) * (1.0 - temp);
+            temp = temp < 0.0 ? 0.0 : temp;
+            const double ratio = nu[j] / nd[j];
+            const double temp2 = temp * (ratio * ratio);
+            const bool direct = temp2 <= 1.4901161193847656e-08; // sqrt(eps)
+            double sq = 0.0;
+#pragma unroll
+            for (int i = K_ + 1; i < 9; i++) sq = sq + M[j][i] * M[j][i];
+            const double root = sqrt(direct ? sq : temp);
+            nd[j] = direct ? root : nd[j];
+            nu[j] = direct ? root : nu[j] * root;
+        }
+    }
+}
+
+// JacobiSVD(A, ComputeFullV).matrixV().col(8) of the 8x9 system A whose row c is M[c][0..8]: the last column of
+// the Q of the column-pivoted Householder QR of (A / scale)^T.  Every loop is unrolled: M lives in registers.
+__device__ __forceinline__ void null_vector_8x9(double M[8][9], double q[9])
+{
+    double scale = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+#pragma unroll
+        for (int r = 0; r < 9; r++)
+            if (fabs(M[c][r]) > scale) scale = fabs(M[c][r]);
+    if (scale == 0.0) scale = 1.0;
+    if (scale != 1.0) { // (x / 1.0 is x)
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int r = 0; r < 9; r++) M[c][r] = M[c][r] / scale;
+    }
+    double nu[8], nd[8], h[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        double sq = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) sq = sq + M[c][r] * M[c][r];
+        nd[c] = nu[c] = sqrt(sq);
+    }
+    colpiv_step9x8<0>(M, nu, nd, h);
+    colpiv_step9x8<1>(M, nu, nd, h);
+    colpiv_step9x8<2>(M, nu, nd, h);
+    colpiv_step9x8<3>(M, nu, nd, h);
+    colpiv_step9x8<4>(M, nu, nd, h);
+    colpiv_step9x8<5>(M, nu, nd, h);
+    colpiv_step9x8<6>(M, nu, nd, h);
+    colpiv_step9x8<7>(M, nu, nd, h);
+    // HouseholderSequence::evalTo, the column it makes of e_8: the reflectors from the last to the first
+#pragma unroll
+    for (int r = 0; r < 9; r++) q[r] = 0.0;
+    q[8] = 1.0;
+    householder_apply9<7>(q, M[7], h[7]);
+    householder_apply9<6>(q, M[6], h[6]);
+    householder_apply9<5>(q, M[5], h[5]);
+    householder_apply9<4>(q, M[4], h[4]);
+    householder_apply9<3>(q, M[3], h[3]);
+    householder_apply9<2>(q, M[2], h[2]);
+    householder_apply9<1>(q, M[1], h[1]);
+    householder_apply9<0>(q, M[0], h[0]);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_fit_kernel(const RansacArgs g)
@@ -517,23 +661,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         return;
     }
 
-    // eightPoint.cpp:243-251: row = [x1*x2, y1*x2, x2, x1*y2, y1*y2, y2, x1, y1, 1]; B = A^T
-    double B[9][8];
+    // eightPoint.cpp:243-251: row = [x1*x2, y1*x2, x2, x1*y2, y1*y2, y2, x1, y1, 1]
+    double M[8][9];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const double2 a = g.x[base + idx[i]], b = g.y[base + idx[i]];
-        B[0][i] = a.x * b.x;
-        B[1][i] = a.y * b.x;
-        B[2][i] = b.x;
-        B[3][i] = a.x * b.y;
-        B[4][i] = a.y * b.y;
-        B[5][i] = b.y;
-        B[6][i] = a.x;
-        B[7][i] = a.y;
-        B[8][i] = 1.0;
+        M[i][0] = a.x * b.x;
+        M[i][1] = a.y * b.x;
+        M[i][2] = b.x;
+        M[i][3] = a.x * b.y;
+        M[i][4] = a.y * b.y;
+        M[i][5] = b.y;
+        M[i][6] = a.x;
+        M[i][7] = a.y;
+        M[i][8] = 1.0;
     }
     double q[9];
-    null_vector_8x9(B, q);
+    null_vector_8x9(M, q);
 
     // eightPoint.cpp:257-265
     const double E[3][3] = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}, {q[6], q[7], q[8]}};
@@ -1691,10 +1835,21 @@ __global__ __launch_bounds__(1024) void ransac_scan_kernel(const int *__restrict
 // ---------------------------------------------------------------------------------------
 // One block per pair.  The point set is the winner's inlier list when it has at least 8 entries,
 // otherwise all correspondences of the pair (scene.cpp:264-298), otherwise nothing.
-//   1. The smallest right singular vector of the n x 9 matrix A (eightPoint.cpp:66-86) is the
-//      eigenvector of the smallest eigenvalue of A^T A: the 45 sums are reduced over the block in a
-//      fixed tree order, then a cyclic Jacobi eigen-iteration runs on the 9 x 9 matrix in LDS
-//      (threads 0..8 own one row / column element each per rotation).
+//   1. matrixV().col(8) of JacobiSVD(A, ComputeFullV) for the n x 9 matrix A (eightPoint.cpp:66-86), by
+//      Eigen's route, so that its sign -- which orders the four candidates -- is Eigen's, and without squaring
+//      the condition number: for n > 9 the column-pivoted Householder QR of A / max|A_ij|, then two-sided
+//      Jacobi sweeps on the 9 x 9 factor R with V starting from the column permutation; for n = 9 the sweeps
+//      on A itself; for n = 8 the last column of the Q of A^T's factorisation (as the fit kernel does).
+//      The factorisation keeps no copy of A.  A reflector changes row r of the remaining columns by
+//      (r's entry in the pivot column / den) * (tau * tmp_j), with den, tau and tmp_j the same for all rows,
+//      so a row's state after k steps follows from its two points and 9 k block-wide scalars kept in LDS:
+//      every step, each thread rebuilds its rows' state and adds their products with the pivot column to nine
+//      sums (reduced over the block in a fixed order); thread 0 turns the sums into the step's reflector,
+//      the row of R and the downdated column norms (recomputed by one more pass where Eigen's rule asks).
+//      The sweeps run in one wave on R in LDS (lanes 0..8 own one element of the two rows / columns a
+//      rotation touches; every lane works the rotation out for itself from the same four elements).
+//      Sums over rows are taken in the block's order, not Eigen's, and tmp_j is formed from the raw sums:
+//      agreement with the CPU restatement is to rounding (poses to 1e-8 in the tests), not bit for bit.
 //   2. Thread 0: essential matrix -> 3x3 SVD -> the four (R, T) candidates (eightPoint.cpp:88-128).
 //   3. All threads: cheirality vote over all n points, first strict maximum (eightPoint.cpp:130-181).
 //   4. All threads: triangulation of all n points with the float cast of lambda (eightPoint.cpp:189-220).
@@ -1704,10 +1859,205 @@ struct RefitArgs {
     double *points; // [total][3]; pair p at corrOff[p]
 };
 
+struct RefitQr {
+    double R[9][9];    // the factor's rows as they are finished; then the work matrix of the sweeps
+    double V[9][9];
+    double tmpc[9][9]; // [m][j]: tau_m * tmp of the column at position j in step m
+    double invden[9];  // 1 / (c0 - beta) of step m, 0 for a step without a reflector
+    double nu[9], nd[9]; // column norms: updated, and as last computed directly
+    double rowK[9];
+    double G[9];
+    double red[4][9];
+    double scale;
+    int transp[9];
+    int direct; // bit j: column j's norm has to be recomputed after this step
+};
+
+// A value loaded from LDS at an address that is the same in every lane is uniform to the compiler.  amdclang 22
+// turned a select between two integer constants on an fp64 comparison of two such values (the pivot of step 7
+// below: 7 or 8) into s_cselect_b32 on SCC without ever moving the v_cmp's result into SCC, so the select read
+// whatever the last exec-mask instruction had left there (scripts/scan_scc_select.py finds the pattern in the
+// ISA).  Passing an operand through an empty asm makes it a per-lane value and the select a v_cndmask.
+__device__ __forceinline__ double per_lane(double v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ void refit_block_sum(RefitQr &S, double acc[9], int cnt, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int e = 0; e < 9; e++) {
+        if (e < cnt) {
+            double v = acc[e];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+            if (lane == 0) S.red[wave][e] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < cnt) S.G[tid] = (S.red[0][tid] + S.red[1][tid]) + (S.red[2][tid] + S.red[3][tid]);
+    __syncthreads();
+}
+
+// Row (a, b) of A / scale after the first K_ steps of the factorisation, columns in their current positions.
+template <int K_>
+__device__ __forceinline__ void refit_row_state(const RefitQr &S, double2 a, double2 b, double cur[9])
+{
+    cur[0] = a.x * b.x;
+    cur[1] = a.y * b.x;
+    cur[2] = b.x;
+    cur[3] = a.x * b.y;
+    cur[4] = a.y * b.y;
+    cur[5] = b.y;
+    cur[6] = a.x;
+    cur[7] = a.y;
+    cur[8] = 1.0;
+    const double scale = S.scale;
+    if (scale != 1.0) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) cur[j] = cur[j] / scale;
+    }
+#pragma unroll
+    for (int m = 0; m < K_; m++) {
+        const int t = S.transp[m];
+#pragma unroll
+        for (int j = m + 1; j < 9; j++) {
+            const bool sw = t == j;
+            const double u = cur[m], v = cur[j];
+            cur[m] = sw ? v : u;
+            cur[j] = sw ? u : v;
+        }
+        const double ess = cur[m] * S.invden[m];
+#pragma unroll
+        for (int j = m + 1; j < 9; j++) cur[j] = cur[j] - S.tmpc[m][j] * ess;
+    }
+}
+
+// Squared norms over rows >= K_ of the columns at positions K_.. after K_ steps -> S.G[j - K_].
+template <int K_, typename RowFn>
+__device__ __forceinline__ void refit_colsq_pass(RefitQr &S, int n, int tid, RowFn row)
+{
+    double acc[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) acc[e] = 0.0;
+    for (int r = tid; r < n; r += 256) {
+        if (r < K_) continue;
+        double2 a, b;
+        row(r, a, b);
+        double cur[9];
+        refit_row_state<K_>(S, a, b, cur);
+#pragma unroll
+        for (int j = K_; j < 9; j++) acc[j - K_] += cur[j] * cur[j];
+    }
+    refit_block_sum(S, acc, 9 - K_, tid);
+}
+
+// Step K_ of ColPivHouseholderQR::computeInPlace on the n x 9 matrix.
+template <int K_, typename RowFn>
+__device__ __forceinline__ void refit_qr_step(RefitQr &S, int n, int tid, RowFn row)
+{
+    if (tid == 0) { // the column of the largest updated norm, the first of equals, comes to position K_
+        int biggest = K_;
+        double bn = per_lane(S.nu[K_]);
+        for (int j = K_ + 1; j < 9; j++) {
+            const double nj = per_lane(S.nu[j]);
+            if (nj > bn) {
+                bn = nj;
+                biggest = j;
+            }
+        }
+        S.transp[K_] = biggest;
+        if (biggest != K_) {
+            double t = S.nu[K_];
+            S.nu[K_] = S.nu[biggest];
+            S.nu[biggest] = t;
+            t = S.nd[K_];
+            S.nd[K_] = S.nd[biggest];
+            S.nd[biggest] = t;
+            for (int i = 0; i < K_; i++) { // the rows of R above move with their columns
+                t = S.R[i][K_];
+                S.R[i][K_] = S.R[i][biggest];
+                S.R[i][biggest] = t;
+            }
+        }
+    }
+    __syncthreads();
+    double acc[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) acc[e] = 0.0;
+    const int tK = S.transp[K_];
+    for (int r = tid; r < n; r += 256) {
+        if (r < K_) continue;
+        double2 a, b;
+        row(r, a, b);
+        double cur[9];
+        refit_row_state<K_>(S, a, b, cur);
+#pragma unroll
+        for (int j = K_ + 1; j < 9; j++) {
+            const bool sw = tK == j;
+            const double u = cur[K_], v = cur[j];
+            cur[K_] = sw ? v : u;
+            cur[j] = sw ? u : v;
+        }
+        if (r == K_) {
+#pragma unroll
+            for (int j = K_; j < 9; j++) S.rowK[j] = cur[j];
+        } else {
+#pragma unroll
+            for (int j = K_; j < 9; j++) acc[j - K_] += cur[K_] * cur[j];
+        }
+    }
+    refit_block_sum(S, acc, 9 - K_, tid); // G[0] = |tail|^2, G[j - K_] = tail . column j
+    if (tid == 0) {
+        const double c0 = S.rowK[K_], tailSqNorm = S.G[0];
+        double tau, beta, invden;
+        if (tailSqNorm <= SFM_DBL_MIN) {
+            tau = 0.0;
+            beta = c0;
+            invden = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tailSqNorm);
+            if (c0 >= 0.0) beta = -beta;
+            invden = 1.0 / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        S.invden[K_] = invden;
+        for (int j = 0; j < K_; j++) S.R[K_][j] = 0.0;
+        S.R[K_][K_] = beta;
+        int direct = 0;
+        for (int j = K_ + 1; j < 9; j++) {
+            const double tmp = S.G[j - K_] * invden + S.rowK[j];
+            const double rkj = S.rowK[j] - tau * tmp;
+            S.R[K_][j] = rkj;
+            S.tmpc[K_][j] = tau * tmp;
+            if (S.nu[j] != 0.0) { // the norm downdate of LAPACK's xGEQPF, as Eigen applies it
+                double temp = fabs(rkj) / S.nu[j];
+                temp = (1.0 + temp) * (1.0 - temp);
+                temp = temp < 0.0 ? 0.0 : temp;
+                const double ratio = S.nu[j] / S.nd[j];
+                const double temp2 = per_lane(temp * (ratio * ratio));
+                if (temp2 <= 1.4901161193847656e-08) direct |= 1 << j;
+                else S.nu[j] = S.nu[j] * sqrt(temp);
+            }
+        }
+        S.direct = direct;
+    }
+    __syncthreads();
+    if constexpr (K_ < 8) {
+        if (S.direct) { // the same for the whole block
+            refit_colsq_pass<K_ + 1>(S, n, tid, row);
+            if (tid > K_ && tid < 9 && ((S.direct >> tid) & 1)) S.nd[tid] = S.nu[tid] = sqrt(S.G[tid - K_ - 1]);
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, const RefitArgs rf)
 {
-    __shared__ double red[4][45];
-    __shared__ double M[9][9], V[9][9];
+    __shared__ RefitQr S;
+    __shared__ double qs[9];
     __shared__ double cand[2][9], T12s[3];
     __shared__ int cnt4[4][4];
     __shared__ int chosen;
@@ -1725,91 +2075,180 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
         if (tid == 0) rf.used[p] = 0;
         return;
     }
+    auto row = [&](int r, double2 &a, double2 &b) __attribute__((always_inline)) {
+        const int64_t at = base + (useInl ? list[r] : r);
+        a = g.x[at];
+        b = g.y[at];
+    };
 
-    // 1. A^T A
-    double acc[45];
+    // 1. the right singular vector of the smallest singular value, Eigen's way
+    if (n == 8) {
+        if (tid == 0) {
+            double M[8][9], q[9];
 #pragma unroll
-    for (int e = 0; e < 45; e++) acc[e] = 0.0;
-    for (int k = tid; k < n; k += 256) {
-        const int64_t at = base + (useInl ? list[k] : k);
-        const double2 a = g.x[at], b = g.y[at];
-        const double r[9] = {a.x * b.x, a.y * b.x, b.x, a.x * b.y, a.y * b.y, b.y, a.x, a.y, 1.0};
-        int e = 0;
+            for (int i = 0; i < 8; i++) {
+                double2 a, b;
+                row(i, a, b);
+                M[i][0] = a.x * b.x;
+                M[i][1] = a.y * b.x;
+                M[i][2] = b.x;
+                M[i][3] = a.x * b.y;
+                M[i][4] = a.y * b.y;
+                M[i][5] = b.y;
+                M[i][6] = a.x;
+                M[i][7] = a.y;
+                M[i][8] = 1.0;
+            }
+            null_vector_8x9(M, q);
 #pragma unroll
-        for (int i = 0; i < 9; i++)
+            for (int i = 0; i < 9; i++) qs[i] = q[i];
+        }
+    } else {
+        { // scale = the largest |A_ij| (1 for a matrix of zeros)
+            double mx = 0.0;
+            for (int r = tid; r < n; r += 256) {
+                double2 a, b;
+                row(r, a, b);
+                const double e[9] = {a.x * b.x, a.y * b.x, b.x, a.x * b.y, a.y * b.y, b.y, a.x, a.y, 1.0};
 #pragma unroll
-            for (int j = i; j < 9; j++) acc[e++] += r[i] * r[j];
-    }
+                for (int j = 0; j < 9; j++)
+                    if (fabs(e[j]) > mx) mx = fabs(e[j]);
+            }
 #pragma unroll
-    for (int e = 0; e < 45; e++) {
-        double v = acc[e];
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double o = __shfl_down(mx, d, 64);
+                if (o > mx) mx = o;
+            }
+            if (lane == 0) S.red[wave][0] = mx;
+            __syncthreads();
+            if (tid == 0) {
+                double m = S.red[0][0];
+                for (int w = 1; w < 4; w++)
+                    if (S.red[w][0] > m) m = S.red[w][0];
+                S.scale = (m == 0.0) ? 1.0 : m;
+            }
+            __syncthreads();
+        }
+        if (n == 9) { // square: the sweeps run on A / scale itself, V starts as the identity
+            if (tid < 9) {
+                double2 a, b;
+                row(tid, a, b);
+                double cur[9];
+                refit_row_state<0>(S, a, b, cur);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-        if (lane == 0) red[wave][e] = v;
-    }
-    __syncthreads();
-    if (tid < 81) {
-        const int i = tid / 9, j = tid % 9;
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        const int e = a * 9 - a * (a - 1) / 2 + (b - a);
-        M[i][j] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        V[i][j] = (i == j) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-
-    // cyclic Jacobi: M <- J^T M J, V <- V J until no off-diagonal element matters.  One wave does it (lanes
-    // 0..8 own one row / column element each per rotation; every lane works the rotation out for itself from
-    // the same three elements), so the 36 rotations of a sweep need no block barrier: the LDS operations of a
-    // wave are carried out in order.
-    if (wave == 0) {
-        auto wave_sync = [&]() __attribute__((always_inline)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        for (int sweep = 0; sweep < 40; sweep++) {
-            bool any = false;
-            for (int pp = 0; pp < 8; pp++) {
-                for (int qq = pp + 1; qq < 9; qq++) {
-                    wave_sync();
-                    const double apq = M[pp][qq], app = M[pp][pp], aqq = M[qq][qq];
-                    double c = 1.0, sn = 0.0;
-                    if (apq != 0.0 && fabs(apq) > 1e-17 * sqrt(fabs(app * aqq))) {
-                        const double theta = (aqq - app) / (2.0 * apq);
-                        const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        c = 1.0 / sqrt(1.0 + t * t);
-                        sn = t * c;
-                        any = true;
-                    }
-                    if (sn != 0.0) { // the same in every lane
-                        if (lane < 9) { // columns pp, qq of M and V, element lane
-                            const double mp = M[lane][pp], mq = M[lane][qq], vp = V[lane][pp], vq = V[lane][qq];
-                            M[lane][pp] = c * mp - sn * mq;
-                            M[lane][qq] = sn * mp + c * mq;
-                            V[lane][pp] = c * vp - sn * vq;
-                            V[lane][qq] = sn * vp + c * vq;
-                        }
+                for (int j = 0; j < 9; j++) {
+                    S.R[tid][j] = cur[j];
+                    S.V[tid][j] = (tid == j) ? 1.0 : 0.0;
+                }
+            }
+        } else {
+            refit_colsq_pass<0>(S, n, tid, row);
+            if (tid < 9) S.nd[tid] = S.nu[tid] = sqrt(S.G[tid]);
+            __syncthreads();
+            refit_qr_step<0>(S, n, tid, row);
+            refit_qr_step<1>(S, n, tid, row);
+            refit_qr_step<2>(S, n, tid, row);
+            refit_qr_step<3>(S, n, tid, row);
+            refit_qr_step<4>(S, n, tid, row);
+            refit_qr_step<5>(S, n, tid, row);
+            refit_qr_step<6>(S, n, tid, row);
+            refit_qr_step<7>(S, n, tid, row);
+            refit_qr_step<8>(S, n, tid, row);
+            if (tid == 0) { // colsPermutation(): the transpositions applied on the right of the identity
+                int perm[9];
+                for (int i = 0; i < 9; i++) perm[i] = i;
+                for (int k = 0; k < 9; k++) {
+                    const int t = perm[k];
+                    perm[k] = perm[S.transp[k]];
+                    perm[S.transp[k]] = t;
+                }
+                for (int i = 0; i < 9; i++)
+                    for (int j = 0; j < 9; j++) S.V[i][j] = (i == perm[j]) ? 1.0 : 0.0;
+            }
+        }
+        __syncthreads();
+        // JacobiSVD's sweeps on the 9 x 9 work matrix (p = 1..8, q = 0..p-1), in one wave: no block barrier
+        if (wave == 0) {
+            auto wave_sync = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
+            double maxDiag = 0.0;
+            for (int i = 0; i < 9; i++)
+                if (fabs(S.R[i][i]) > maxDiag) maxDiag = fabs(S.R[i][i]);
+            for (int sweep = 0; sweep < 1000; sweep++) {
+                bool finished = true;
+                for (int pp = 1; pp < 9; pp++) {
+                    for (int qq = 0; qq < pp; qq++) {
                         wave_sync();
-                        if (lane < 9) { // rows pp, qq of M, element lane
-                            const double mp = M[pp][lane], mq = M[qq][lane];
-                            M[pp][lane] = c * mp - sn * mq;
-                            M[qq][lane] = sn * mp + c * mq;
+                        const double wpq = S.R[pp][qq], wqp = S.R[qq][pp];
+                        const double pm = (2.0 * SFM_DBL_EPS) * maxDiag;
+                        const double threshold = (SFM_DBL_MIN < pm) ? pm : SFM_DBL_MIN;
+                        if (fabs(wpq) > threshold || fabs(wqp) > threshold) { // the same in every lane
+                            finished = false;
+                            JRot jl, jr;
+                            real_2x2_jacobi_svd(S.R[pp][pp], wpq, wqp, S.R[qq][qq], jl, jr);
+                            const bool il = jl.c == 1.0 && jl.s == 0.0, ir = jr.c == 1.0 && -jr.s == 0.0;
+                            if (lane < 9) { // rows pp, qq of the work matrix
+                                double x = S.R[pp][lane], y = S.R[qq][lane];
+                                rotate_pair(x, y, jl.c, jl.s, il);
+                                S.R[pp][lane] = x;
+                                S.R[qq][lane] = y;
+                            }
+                            wave_sync();
+                            if (lane < 9) { // columns pp, qq of the work matrix and of V
+                                double x = S.R[lane][pp], y = S.R[lane][qq];
+                                rotate_pair(x, y, jr.c, -jr.s, ir);
+                                S.R[lane][pp] = x;
+                                S.R[lane][qq] = y;
+                                x = S.V[lane][pp];
+                                y = S.V[lane][qq];
+                                rotate_pair(x, y, jr.c, -jr.s, ir);
+                                S.V[lane][pp] = x;
+                                S.V[lane][qq] = y;
+                            }
+                            wave_sync();
+                            const double app = fabs(S.R[pp][pp]), aqq = fabs(S.R[qq][qq]);
+                            const double mx = (app < aqq) ? aqq : app;
+                            if (maxDiag < mx) maxDiag = mx;
                         }
                     }
                 }
+                if (finished) break;
             }
-            if (!any) break;
+            wave_sync();
+            if (lane == 0) { // singular values, descending by selection (the first of equal maxima); column 8
+                double sv[9];
+                int col[9];
+                for (int i = 0; i < 9; i++) {
+                    sv[i] = per_lane(fabs(S.R[i][i]) * S.scale);
+                    col[i] = i;
+                }
+                for (int i = 0; i < 9; i++) {
+                    int pos = i;
+                    for (int k = i + 1; k < 9; k++)
+                        if (sv[k] > sv[pos]) pos = k;
+                    if (sv[pos] == 0.0) break;
+                    if (pos != i) {
+                        const double t = sv[i];
+                        sv[i] = sv[pos];
+                        sv[pos] = t;
+                        const int c = col[i];
+                        col[i] = col[pos];
+                        col[pos] = c;
+                    }
+                }
+                for (int i = 0; i < 9; i++) qs[i] = S.V[i][col[8]];
+            }
         }
     }
     __syncthreads();
 
     // 2. candidates
     if (tid == 0) {
-        int best = 0;
-        for (int j = 1; j < 9; j++)
-            if (M[j][j] < M[best][best]) best = j;
         double q[9];
-        for (int i = 0; i < 9; i++) q[i] = V[i][best];
+        for (int i = 0; i < 9; i++) q[i] = qs[i];
         const double E[3][3] = {{q[0], q[1], q[2]}, {q[3], q[4], q[5]}, {q[6], q[7], q[8]}};
         double U[3][3], S[3], W[3][3];
         svd3(E, U, S, W);

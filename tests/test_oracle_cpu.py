@@ -145,21 +145,144 @@ def test_svd3_against_lapack(oracle):
             E = rng.standard_normal((3, 2)) @ rng.standard_normal((2, 3))  # rank 2 (an essential matrix is)
         if k % 50 == 2:
             E = np.outer(rng.standard_normal(3), rng.standard_normal(3))   # rank 1
+        if k % 50 == 3:
+            E = np.zeros((3, 3))
+        if k % 7 == 0:
+            E *= 10.0 ** rng.integers(-200, 200)                            # the scaling by the largest entry
         U, S, V = oracle.svd3(E)
-        assert np.allclose(U @ np.diag(S) @ V.T, E, atol=1e-12)
-        assert np.allclose(S, np.linalg.svd(E, compute_uv=False), atol=1e-12)
-        assert np.allclose(U.T @ U, np.eye(3), atol=1e-9) and np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+        scale = max(np.abs(E).max(), 1e-300)
+        assert np.allclose((U * (S / scale)) @ V.T, E / scale, atol=1e-12)
+        assert np.allclose(S / scale, np.linalg.svd(E / scale, compute_uv=False), atol=1e-12)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-12) and np.allclose(V.T @ V, np.eye(3), atol=1e-12)
         assert S[0] >= S[1] >= S[2] >= 0
+
+
+def test_jacobi_svd_reproduces_the_example_in_eigens_documentation(oracle):
+    """The one output of Eigen's JacobiSVD that is printed where anyone can read it: the example of the class
+    documentation (MatrixXf::Random(3,2) with the library's fixed seed, ComputeThinU | ComputeThinV).  Matrix
+    and printed result are quoted here from that page, not from the reference tree and not fetched (there is
+    no network): three significant digits, which is enough to tell signs and order.  The restated pieces it
+    exercises are the ones the path uses: pivoted Householder QR as the preconditioner, householderQ applied
+    to the identity, the two-sided Jacobi sweeps, the sign fix, the sort."""
+    m = np.array([[0.680375, 0.59688], [-0.211234, 0.823295], [0.566198, -0.604897]])
+    U, S, V = oracle.jacobi_svd_tall(m)
+    assert np.allclose(S, [1.19, 0.899], atol=6e-3)
+    assert np.allclose(U, [[0.388, 0.866], [0.712, -0.0634], [-0.586, 0.496]], atol=6e-4)
+    assert np.allclose(V, [[-0.183, 0.983], [0.983, 0.183]], atol=6e-4)
+    # (the same page prints the least-squares solution for rhs (1, 0, 0): 0.888, 0.496)
+    rhs = np.array([1.0, 0.0, 0.0])
+    assert np.allclose(V @ ((U.T @ rhs) / S), [0.888, 0.496], atol=6e-4)
+
+
+def test_jacobi_svd_tall_against_lapack(oracle):
+    rng = np.random.default_rng(12)
+    for r, c in [(3, 2), (10, 9), (12, 9), (40, 9), (500, 9), (9, 4)]:
+        A = rng.standard_normal((r, c))
+        U, S, V = oracle.jacobi_svd_tall(A)
+        assert np.allclose((U * S) @ V.T, A, atol=1e-11)
+        assert np.allclose(S, np.linalg.svd(A, compute_uv=False), atol=1e-11)
+        assert np.allclose(U.T @ U, np.eye(c), atol=1e-12) and np.allclose(V.T @ V, np.eye(c), atol=1e-12)
+        if c == 9:  # the refit's route to its null vector is this decomposition's last column of V
+            assert np.array_equal(oracle.null_vector(A), V[:, 8])
 
 
 def test_null_vector_against_lapack(oracle):
     rng = np.random.default_rng(2)
-    for n in (8, 8, 8, 9, 20, 200):
+    for n in (8, 8, 8, 9, 10, 20, 200):
         A = rng.standard_normal((n, 9))
+        if n == 10:
+            A *= 1e-120
         q = oracle.null_vector(A)
         v = np.linalg.svd(A)[2][-1]
         assert min(np.abs(q - v).max(), np.abs(q + v).max()) < 1e-9
         assert abs(np.linalg.norm(q) - 1) < 1e-12
+    # a rank-deficient 8x9 system still has a unit vector in its null space as the answer
+    A = rng.standard_normal((8, 9))
+    A[5] = A[2]
+    q = oracle.null_vector(A)
+    assert np.abs(A @ q).max() < 1e-12 and abs(np.linalg.norm(q) - 1) < 1e-12
+
+
+def numpy_vote_ties(x, y, S):
+    """Rows whose largest cheirality count is shared by two or more of the four candidates, counted without
+    any SVD convention: LAPACK factors, the candidate *set* {R1, R2} x {T, -T}, exact depth signs."""
+    n = len(S)
+    xh = np.concatenate([x, np.ones((len(x), 1))], axis=1)
+    yh = np.concatenate([y, np.ones((len(y), 1))], axis=1)
+    tied = np.zeros(n, bool)
+    Wp = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    for h in range(n):
+        a, b = xh[S[h]], yh[S[h]]
+        A = np.stack([np.kron(b[i], a[i]) for i in range(8)])
+        E = np.linalg.svd(A)[2][-1].reshape(3, 3)
+        U, _, Vt = np.linalg.svd(E)
+        votes = []
+        for R in (U @ Wp @ Vt, U @ Wp.T @ Vt):
+            R = R * np.sign(np.linalg.det(R))
+            for T in (U[:, 2], -U[:, 2]):
+                lam = [np.linalg.lstsq(np.stack([-(R @ a[i]), b[i]], axis=1), T, rcond=None)[0] for i in range(8)]
+                votes.append(sum(1 for l in lam if l[0] > 0 and l[1] > 0))
+        tied[h] = sorted(votes)[-1] == sorted(votes)[-2]
+    return tied
+
+
+def test_tied_cheirality_votes_are_common(oracle):
+    """How often the order of the four candidates decides (eightPoint.cpp:296-337 keeps the first strict
+    maximum): the share of sample rows whose top vote is tied, on the RANSAC stress shape (20 000
+    correspondences, 15 % inliers, 4096 rows) and with 50 % and 80 % inliers; how many of the twenty best rows
+    by inlier count, and whether the winner, are among them.  Measured (printed with pytest -s): 21.0 %, 16.1 %,
+    5.1 % of the rows.  The tie count of the restatement is checked against a count that uses LAPACK's factors
+    and no candidate order, on a sample of rows."""
+    report = []
+    for name, ratio, want in (("15 %", 0.15, (0.17, 0.25)), ("50 %", 0.5, (0.12, 0.20)), ("80 %", 0.8, (0.03, 0.08))):
+        tv = synth.two_view(20000, inlier_ratio=ratio, seed=7)
+        S = synth.sample_table(20000, 4096, seed=8)
+        _, cand, votes = oracle.fit_hypotheses_votes(tv["x"], tv["y"], S)
+        top = votes.max(axis=1)
+        tied = (votes == top[:, None]).sum(axis=1) > 1
+        assert np.array_equal(cand, votes.argmax(axis=1))            # the first strict maximum
+        r = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=False)
+        best20 = np.argsort(-r["counts"], kind="stable")[:20]
+        report.append((name, tied.mean(), int(tied[best20].sum()), bool(tied[r["best_h"]]), votes[r["best_h"]].tolist()))
+        assert want[0] < tied.mean() < want[1], report[-1]
+        some = np.arange(0, 4096, 64)
+        assert np.array_equal(tied[some], numpy_vote_ties(tv["x"], tv["y"], S[some]))
+    for name, share, in_top20, winner_tied, winner_votes in report:
+        print(f"inliers {name}: tied rows {100 * share:.1f} %, {in_top20} of the 20 best rows tied, "
+              f"winner tied: {winner_tied} (votes {winner_votes})")
+
+
+def test_refit_route_does_not_square_the_condition_number(oracle):
+    """The refit's null vector (eightPoint.cpp:85-86: JacobiSVD on A itself) on noise-free scenes within 1e-3
+    and 1e-4 of a plane, where sigma_7 / sigma_0 of the n x 9 system is ~1e-4 .. 1e-5 and the exact answer is
+    known (the essential matrix of the planted pose): the restated route (pivoted QR of A, Jacobi sweeps on R)
+    stays near cond * eps; the smallest eigenvector of A^T A -- the route this repository's refit kernel took
+    before -- loses the square of that."""
+    worst_qr = worst_ata = 0.0
+    for seed in range(6):
+        for planar in (1e-3, 1e-4):
+            rng = np.random.default_rng(500 + seed)
+            n = 400
+            K = synth.default_K()
+            Kinv = np.linalg.inv(K)
+            R = synth._rodrigues(rng.standard_normal(3), np.deg2rad(5.0))
+            T = rng.standard_normal(3)
+            T /= np.linalg.norm(T)
+            u = np.stack([rng.uniform(200, 3800, n), rng.uniform(200, 2800, n), np.ones(n)], axis=1)
+            rays = u @ Kinv.T
+            z = 5.0 / (rays @ np.array([0.1, -0.2, 1.0])) * (1.0 + planar * rng.standard_normal(n))
+            X = rays * z[:, None]
+            X2 = X @ R.T + T
+            xh, yh = rays, X2 / X2[:, 2:3]
+            A = np.stack([np.kron(yh[i], xh[i]) for i in range(n)])
+            Tx = np.array([[0, -T[2], T[1]], [T[2], 0, -T[0]], [-T[1], T[0], 0]])
+            e = (Tx @ R).reshape(-1)
+            e /= np.linalg.norm(e)
+            err = lambda q: min(np.abs(q - e).max(), np.abs(q + e).max())
+            worst_qr = max(worst_qr, err(oracle.null_vector(A)))
+            worst_ata = max(worst_ata, err(np.linalg.eigh(A.T @ A)[1][:, 0]))
+    print(f"largest error of the null vector: QR + Jacobi {worst_qr:.2e}, A^T A {worst_ata:.2e}")
+    assert worst_qr < 1e-10 and worst_ata > 30 * worst_qr
 
 
 def test_triangulation_against_lstsq(oracle):
