@@ -100,6 +100,9 @@ def main():
     multi = world > 1 or args.rehearse_gather  # the N > 1 code path
     if multi:
         import torch.distributed as dist
+        if world == 1:  # --rehearse-gather outside a launcher: a group of one
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     ctx = capi.Context(local_rank)
     sim_variant, bound_dtype, bound_peak = BOUNDS[args.bound]
@@ -235,6 +238,17 @@ def main():
     gathered_total = None
     if rank == 0 and multi and gathered is not None:
         gathered_total = int(gathered.total()) if comm is not None else int(gathered[2].shape[0])
+    gather_check = None
+    if multi:
+        gather_check = check_gather(torch, dist, ctx, comm, gathered, imgset, pair_list, total_pairs, total_matches, rank,
+                                    local_rank, args)
+    # the timed region leaves every step's lists on the device (a device-resident pipeline reads them there);
+    # what fetching one step's lists to the host costs is measured once, outside the timed region
+    t0 = time.perf_counter()
+    fetched = res.pairs()
+    fetch_ms = (time.perf_counter() - t0) * 1e3
+    fetch_bytes = int(fetched.nbytes)
+    del fetched
     value = total_pairs * args.steps / elapsed
     flops_per_pair = 2.0 * args.features * args.features * 128
     achieved_tflops = flops_per_pair * len(my_pairs) * args.steps / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
@@ -262,7 +276,10 @@ def main():
             "images": n_images, "features_per_image": args.features, "dim": 128,
             "pairs_total": total_pairs, "pairs_per_gpu": pairs_per_gpu, "parallelism": f"pair-list dp{world}",
             "matches_rank0": int(total_matches), "candidates_rank0": int(cand), "overflow_rank0": int(ovf),
-            "gather": gather_mode, "matches_gathered_on_rank0": gathered_total,
+            "gather": gather_mode, "matches_gathered_on_rank0": gathered_total, "gather_check": gather_check,
+            "lists_left_on_device": True,
+            "fetching_one_steps_lists_rank0": {"ms": round(fetch_ms, 2), "bytes": fetch_bytes,
+                                               "note": "sfm_match_result_pairs into pageable host memory, once, after the timed region"},
             "setup_s": round(gen_s, 2),
             "device_bytes_rank0": {"image_set": imgset.device_bytes(), "matcher_work_buffers_and_lists": res_bytes},
         },
@@ -284,7 +301,7 @@ def main():
 
     # ---- secondary: RANSAC stress shape ------------------------------------------------------
     if not args.no_ransac:
-        out["ransac"] = bench_ransac(ctx, args, rank, world, dist, local_rank)
+        out["ransac"] = bench_ransac(ctx, args, rank, world, dist, local_rank, comm if multi else None)
 
     # ---- secondary: the stages chained on the device (default-run stand-in) --------------------
     if not args.no_pipeline and world == 1:
@@ -300,6 +317,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, desc, pts, out.get("ransac"), pipe_inputs)
 
+    # the figures a reader of the line's tail needs, once more at its very end
+    out["summary"] = {"pairs_per_s": out["value"], "n_gpus": world, "match_sim_kernel_frac_of_mfma_peak": out["roofline"]["frac"],
+                      "ransac_hyps_per_s": out.get("ransac", {}).get("value"),
+                      "cpu_pairs_per_s": out.get("cpu_baseline", {}).get("value"),
+                      "cpu_ransac_hyps_per_s": out.get("cpu_baseline", {}).get("ransac", {}).get("value")}
     if rank == 0:
         sys.stdout.flush()
         line = (json.dumps(out) + "\n").encode()
@@ -313,6 +335,38 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def check_gather(torch, dist, ctx, comm, gathered, imgset, pair_list, total_pairs, local_total, rank, local_rank, args):
+    """N > 1 (or --rehearse-gather): the gathered lists against what the ranks hold.  The total on the root must
+    be the sum of the ranks' totals, and eight pairs sampled over the whole list, matched again on rank 0 alone,
+    must equal their gathered lists.  A mismatch ends the run with an error; a failure of the check itself is
+    reported on the line."""
+    dev = torch.device(f"cuda:{local_rank}")
+    t = torch.tensor([int(local_total)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    want = int(t.item())
+    if rank != 0 or gathered is None:
+        return None
+    try:
+        if comm is not None:
+            got_total = int(gathered.total())
+            starts, cnt = gathered.layout()
+            allp = gathered.pairs()
+        else:
+            starts, cnt = np.asarray(gathered[0]), np.asarray(gathered[1])  # shard.gather_csr(ordered=False)
+            allp = gathered[2].cpu().numpy()
+            got_total = int(allp.shape[0])
+        sample = np.unique(np.linspace(0, total_pairs - 1, 8).astype(np.int64))
+        ref = imgset.match(np.ascontiguousarray(pair_list[sample]), threshold=args.threshold, max_dist_sq=1e8, ratio=args.ratio)
+        roff, rp = ref.offsets(), ref.pairs()
+        ref.close()
+        same = all(np.array_equal(allp[starts[i]:starts[i] + cnt[i]], rp[roff[k]:roff[k + 1]]) for k, i in enumerate(sample))
+    except Exception as e:  # the check, not the gather, failed
+        return {"error": f"{type(e).__name__}: {e}"}
+    if got_total != want or not same:
+        raise SystemExit(f"gather check failed: {got_total} matches on rank 0, the ranks hold {want}; sampled lists equal: {same}")
+    return {"sum_of_rank_totals": want, "sampled_pairs_equal_to_single_gpu_lists": int(len(sample))}
 
 
 def measured_traffic(pairs_per_launch, bound="int8"):
@@ -643,7 +697,7 @@ def ransac_valu_profile(mfma):
     return None, None, None, None
 
 
-def bench_ransac(ctx, args, rank, world, dist, local_rank):
+def bench_ransac(ctx, args, rank, world, dist, local_rank, comm=None):
     """hypotheses scored/s on one batch of ransac_pairs pairs/GPU x ransac_corr correspondences (15 % inliers)
     x ransac_hyps hypotheses, inputs resident on the device; at N = 1 also rows at inlier ratios where RANSAC
     finds its model, with the pre-test on and off."""
@@ -653,16 +707,23 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
     dev = torch.device(f"cuda:{local_rank}")
     K = synth.default_K()
 
-    def measure(pairs, distinct, ratio, adaptive, filt, steps, seed, loss=0):
+    from sfm_amd import capi
+    gathered_info = {}
+
+    def measure(pairs, distinct, ratio, adaptive, filt, steps, seed, loss=0, gather_total=0):
         xd, yd, sd = ransac_inputs(torch, dev, pairs, distinct, n, H, ratio, seed)
         off = np.arange(pairs + 1, dtype=np.int64) * n
         ctx.set_option("ransac_filter", filt)
         batch = None
+        g = None
 
         def step():
-            nonlocal batch
+            nonlocal batch, g
             batch = ctx.ransac_batch(off, None, None, K, None, H, max_sq_err=1.0, success_prob=0.999, adaptive=adaptive,
                                      batch=batch, device_ptrs=(xd.data_ptr(), yd.data_ptr(), sd.data_ptr()), loss=loss)
+            if gather_total:  # winners and inlier lists of every rank to rank 0 (RCCL), inside the step
+                g = comm.gather_ransac(batch, gather_total, gathered=g)
+                g.wait()
             ctx.synchronize()
 
         step()
@@ -682,15 +743,29 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         best = batch.best()
+        if g is not None:
+            if rank == 0:  # what arrived: every pair of the whole list, and this rank's own share unchanged
+                r = g.ransac()
+                mine = capi.shard_indices(gather_total, rank, world)
+                ok = (len(r["best_h"]) == gather_total and np.array_equal(r["best_h"][mine], best["best_h"])
+                      and np.array_equal(r["count"][mine], best["count"]) and int(r["inlier_offsets"][-1]) == int(g.total()))
+                if not ok:
+                    raise SystemExit("RANSAC gather check failed: rank 0's own results differ from their gathered copy")
+                gathered_info.update({"pairs_gathered_on_rank0": int(gather_total), "inliers_gathered_on_rank0": int(g.total()),
+                                      "rank0_share_equal_to_its_batch": True})
+            g.close()
         batch.close()
         ctx.set_option("ransac_filter", 1)
         del xd, yd, sd
         return el, kms, launches, best
 
     steps = max(1, args.steps)
-    el, kms, launches, best = measure(P, args.ransac_distinct, 0.15, True, 1, steps, rank)
-    hyps = P * H * steps * world
-    pairs_s = P * steps * world / el
+    n_total = P * world
+    if comm is not None:  # the rank's share of a list of P pairs per GPU, dealt in blocks of 64 like the matcher's
+        P = int(capi.shard_count(n_total, rank, world))
+    el, kms, launches, best = measure(P, args.ransac_distinct, 0.15, True, 1, steps, rank, gather_total=n_total if comm is not None else 0)
+    hyps = n_total * H * steps
+    pairs_s = n_total * steps / el
     mfma_on = int(os.environ.get("SFM_RANSAC_MFMA", "1")) != 0  # the library's default; the stress shape meets its conditions
     per_grp, grp, extra, src = ransac_valu_profile(mfma_on)
     valu = None
@@ -716,7 +791,10 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank):
         "score_kernel_ms_per_step": round(kms / steps, 3), "score_kernel_launches_per_step": launches // steps,
         "roofline": valu,
         "mean_best_inliers": float(np.mean(best["count"])),
+        "gather": ("library: winners' records and inlier lists of every rank to rank 0 inside the step (sfm_ransac_gather)"
+                   if comm is not None else "none"),
     }
+    out.update(gathered_info)
     if world == 1 and not args.no_regimes:
         rows = []
         for ratio in (0.5, 0.8):

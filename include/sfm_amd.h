@@ -28,6 +28,7 @@ extern "C" {
 #define SFM_ERR_UNSUPPORTED 4  /* valid request this build has no kernel for    */
 #define SFM_ERR_CAPACITY 5     /* caller's output buffer too small              */
 #define SFM_ERR_HIP 6          /* a HIP runtime call failed; see sfm_last_error */
+#define SFM_ERR_TIMEOUT 7      /* a multi-GPU exchange did not finish in time   */
 
 /* match/match.hpp:18-46: the two similarity metrics the reference provides.
  * (MATCHING_OPTIONS::similarityMetric holding anything else has no kernel.) */
@@ -467,6 +468,15 @@ int64_t sfm_shard_count(int64_t n_pairs, int rank, int world);
 int sfm_shard_indices(int64_t n_pairs, int rank, int world, int64_t *indices_out);
 int sfm_shard_layout(int64_t n_pairs, int world, const int32_t *counts, int64_t max_owned,
                      int64_t *starts_out, int32_t *counts_out);
+/* Host-only: the rank-major buffers of a RANSAC gather (see sfm_ransac_gather)
+ * put into the order of the whole pair list.  records[world][max_owned] of 120
+ * bytes {int32 best row, inlier count, iterations, 0; double error sum; double
+ * pose12[12]}, counts[world][max_owned], lists = rank 0's inlier lists, then rank
+ * 1's, ...  Outputs as sfm_gathered_ransac's; each may be NULL. */
+int sfm_shard_unpack_ransac(int64_t n_pairs, int world, const int32_t *counts, int64_t max_owned,
+                            const void *records, const int32_t *lists, int32_t *best_hyp_out,
+                            int32_t *best_count_out, double *best_toterr_out, int32_t *iterations_out,
+                            double *pose12_out, int64_t *inlier_offsets_out, int32_t *inliers_out);
 /* One process per GPU: rank 0 makes an id (128 bytes) and hands it to the other
  * ranks by any channel; every rank then creates its communicator (collective). */
 int sfm_comm_unique_id(void *id128_out);
@@ -502,11 +512,35 @@ int sfm_match_batch_multi(int n, sfm_comm *const *comms, const sfm_imageset *con
  * lists themselves, pairs_out[2 * total] (root only; synchronises); device views
  * (pairs: root only, else NULL; counts[world][max_owned]). */
 int sfm_gathered_wait(sfm_gathered *g);
+/* The same with a time limit in milliseconds (<= 0: none): SFM_ERR_TIMEOUT when
+ * the exchange has not finished by then -- e.g. a rank that never joined it --
+ * instead of a process that hangs.  The waits inside the gather calls and the
+ * accessors use the context option "comm_timeout_ms" (default 120000, 0: none). */
+int sfm_gathered_wait_timeout(sfm_gathered *g, int64_t timeout_ms);
 int sfm_gathered_total(sfm_gathered *g, int64_t *total_out, int64_t *per_rank_totals_out);
 int sfm_gathered_layout(sfm_gathered *g, int64_t *starts_out, int32_t *counts_out);
 int sfm_gathered_pairs(sfm_gathered *g, int32_t *pairs_out);
 int sfm_gathered_device(sfm_gathered *g, const int32_t **pairs_device, const int32_t **counts_device);
 void sfm_gathered_destroy(sfm_gathered *g);
+/* RANSAC results of a sharded pair list (no counterpart in the reference, whose
+ * one call per pair is submodules/scene.cpp:261): `local` is the batch this rank
+ * ran over the pairs sfm_shard_indices gives it, in that order.  The winners'
+ * records (row, inlier count, error sum, iterations, pose) and the ascending
+ * inlier lists go to the root the way the match lists do: an all-gather of the
+ * per-pair counts, then point-to-point transfers.  sfm_gathered_wait, _total
+ * (inliers in all and per rank), _layout and _destroy serve the object as they
+ * serve a matcher's; sfm_gathered_ransac (root only; synchronises) returns the
+ * results in the order of the whole pair list: best_hyp, best_count, toterr,
+ * iterations [n_pairs_total], pose12 [n_pairs_total][12] (R row-major, then T;
+ * identity for a pair without a winner), the inlier lists as CSR
+ * (inlier_offsets [n_pairs_total + 1], inliers [total]).  Outputs may be NULL. */
+int sfm_ransac_gather(sfm_comm *comm, sfm_ransac_batch *local, int64_t n_pairs_total, int root,
+                      sfm_gathered **gathered_inout);
+int sfm_ransac_gather_local(int n, sfm_comm *const *comms, sfm_ransac_batch *const *locals,
+                            int64_t n_pairs_total, int root, sfm_gathered **gathered_inout);
+int sfm_gathered_ransac(sfm_gathered *g, int32_t *best_hyp_out, int32_t *best_count_out,
+                        double *best_toterr_out, int32_t *iterations_out, double *pose12_out,
+                        int64_t *inlier_offsets_out, int32_t *inliers_out);
 
 #ifdef __cplusplus
 }

@@ -15,13 +15,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP = range(7)
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_TIMEOUT = range(8)
 METRIC_COSINE, METRIC_DOT, METRIC_L2 = 0, 1, 2
 MATCH_TWO_SIDED = 0
 LOSS_REPROJECTION, LOSS_SAMPSON = 0, 1
 
 _STATUS_NAMES = {1: "invalid argument", 2: "no gfx950 device", 3: "out of memory", 4: "unsupported",
-                 5: "output capacity too small", 6: "HIP runtime error"}
+                 5: "output capacity too small", 6: "HIP runtime error", 7: "multi-GPU exchange timed out"}
 
 # Every symbol include/sfm_amd.h declares.
 EXPORTED_SYMBOLS = [
@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "sfm_shard_count", "sfm_shard_indices", "sfm_shard_layout", "sfm_comm_unique_id", "sfm_comm_create",
     "sfm_comm_create_local", "sfm_comm_rank", "sfm_comm_destroy", "sfm_match_gather", "sfm_match_gather_local",
     "sfm_match_batch_multi", "sfm_gathered_wait", "sfm_gathered_total", "sfm_gathered_layout", "sfm_gathered_pairs", "sfm_gathered_device",
-    "sfm_gathered_destroy",
+    "sfm_gathered_destroy", "sfm_gathered_wait_timeout", "sfm_ransac_gather", "sfm_ransac_gather_local", "sfm_gathered_ransac", "sfm_shard_unpack_ransac",
 ]
 
 
@@ -153,6 +153,11 @@ def lib() -> C.CDLL:
         L.sfm_gathered_device.argtypes = [vp, P(vp), P(vp)]
         L.sfm_gathered_destroy.argtypes = [vp]
         L.sfm_gathered_destroy.restype = None
+        L.sfm_gathered_wait_timeout.argtypes = [vp, i64]
+        L.sfm_ransac_gather.argtypes = [vp, vp, i64, i32, P(vp)]
+        L.sfm_ransac_gather_local.argtypes = [i32, P(vp), P(vp), i64, i32, P(vp)]
+        L.sfm_gathered_ransac.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sfm_shard_unpack_ransac.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -180,6 +185,31 @@ def shard_layout(n_pairs: int, world: int, counts: np.ndarray):
     if rc != OK:
         raise SfmError(rc, "sfm_shard_layout")
     return starts[:n_pairs], cnt[:n_pairs]
+
+
+RANSAC_RECORD = np.dtype([("best_h", np.int32), ("count", np.int32), ("iterations", np.int32), ("pad", np.int32),
+                          ("toterr", np.float64), ("pose12", np.float64, (12,))])  # 120 bytes, as the gather moves them
+
+
+def shard_unpack_ransac(n_pairs: int, world: int, counts, records, lists):
+    """sfm_shard_unpack_ransac (host only): rank-major gather buffers -> results in the order of the whole list."""
+    counts = np.ascontiguousarray(counts, np.int32).reshape(world, -1)
+    records = np.ascontiguousarray(records, RANSAC_RECORD).reshape(world, -1)
+    lists = np.ascontiguousarray(lists, np.int32)
+    n = int(n_pairs)
+    best = np.zeros(max(n, 1), np.int32)
+    cnt = np.zeros(max(n, 1), np.int32)
+    err = np.zeros(max(n, 1), np.float64)
+    it = np.zeros(max(n, 1), np.int32)
+    pose = np.zeros((max(n, 1), 12), np.float64)
+    off = np.zeros(n + 1, np.int64)
+    inl = np.zeros(max(len(lists), 1), np.int32)
+    rc = lib().sfm_shard_unpack_ransac(n, int(world), _ptr(counts), counts.shape[1], _ptr(records), _ptr(lists) if len(lists) else None,
+                                       _ptr(best), _ptr(cnt), _ptr(err), _ptr(it), _ptr(pose), _ptr(off), _ptr(inl))
+    if rc != OK:
+        raise SfmError(rc, "sfm_shard_unpack_ransac")
+    return dict(best_h=best[:n], count=cnt[:n], toterr=err[:n], iterations=it[:n], pose12=pose[:n], inlier_offsets=off,
+                inliers=inl[:int(off[n])])
 
 
 class Comm:
@@ -223,6 +253,13 @@ class Comm:
         g.n_total, g.root = int(n_pairs_total), int(root)
         return g
 
+    def gather_ransac(self, batch: "RansacBatch", n_pairs_total: int, root: int = 0, gathered: "Gathered" = None) -> "Gathered":
+        """sfm_ransac_gather: the winners and inlier lists of this rank's share of the pair list to the root."""
+        g = gathered if gathered is not None else Gathered(self)
+        self.ctx.check(lib().sfm_ransac_gather(self._h, batch._h, int(n_pairs_total), int(root), C.byref(g._h)))
+        g.n_total, g.root = int(n_pairs_total), int(root)
+        return g
+
     def close(self):
         if self._h:
             lib().sfm_comm_destroy(self._h)
@@ -250,6 +287,33 @@ class Gathered:
         """Blocks until the lists are in place (root) and the local result may be overwritten."""
         if self._h:
             self.ctx.check(lib().sfm_gathered_wait(self._h))
+
+    def wait_timeout(self, timeout_ms: int) -> bool:
+        """True when the gather has finished, False when timeout_ms passed first (it stays in flight)."""
+        if not self._h:
+            return True
+        rc = lib().sfm_gathered_wait_timeout(self._h, int(timeout_ms))
+        if rc == ERR_TIMEOUT:
+            return False
+        self.ctx.check(rc)
+        return True
+
+    def ransac(self):
+        """Gathered RANSAC results in the order of the whole pair list (root only): dict(best_h, count, toterr,
+        iterations, pose12 [n,12], inlier_offsets [n+1], inliers)."""
+        n = self.n_total
+        tot = self.total()
+        best = np.zeros(max(n, 1), np.int32)
+        cnt = np.zeros(max(n, 1), np.int32)
+        err = np.zeros(max(n, 1), np.float64)
+        it = np.zeros(max(n, 1), np.int32)
+        pose = np.zeros((max(n, 1), 12), np.float64)
+        off = np.zeros(n + 1, np.int64)
+        inl = np.zeros(max(tot, 1), np.int32)
+        self.ctx.check(lib().sfm_gathered_ransac(self._h, _ptr(best), _ptr(cnt), _ptr(err), _ptr(it), _ptr(pose), _ptr(off),
+                                                 _ptr(inl)))
+        return dict(best_h=best[:n], count=cnt[:n], toterr=err[:n], iterations=it[:n], pose12=pose[:n],
+                    inlier_offsets=off, inliers=inl[:tot])
 
     def total(self) -> int:
         t = C.c_int64(0)
@@ -305,6 +369,20 @@ def match_batch_multi(comms, sets, pair_list, threshold=0.5, max_dist_sq=1e8, me
         gathered[i]._h = C.c_void_p(gh[i])
         gathered[i].n_total, gathered[i].root = len(pl), root
     return results, gathered
+
+
+def ransac_gather_local(comms, batches, n_pairs_total, root=0, gathered=None):
+    """sfm_ransac_gather_local: one process, len(comms) devices; batches[i] ran rank i's share."""
+    n = len(comms)
+    gathered = gathered if gathered is not None else [Gathered(c) for c in comms]
+    ch = (C.c_void_p * n)(*[c._h for c in comms])
+    bh = (C.c_void_p * n)(*[b._h for b in batches])
+    gh = (C.c_void_p * n)(*[g._h for g in gathered])
+    comms[0].ctx.check(lib().sfm_ransac_gather_local(n, ch, bh, int(n_pairs_total), int(root), gh))
+    for i in range(n):
+        gathered[i]._h = C.c_void_p(gh[i])
+        gathered[i].n_total, gathered[i].root = int(n_pairs_total), int(root)
+    return gathered
 
 
 def _chain_outputs(S, n_tracks):

@@ -62,6 +62,7 @@ struct sfm_ctx {
     // (RANSAC.cpp:189-196), checked on the device between slices of sample rows (0 = none)
     uint64_t ransac_seed = 0;
     int64_t ransac_max_time_ms = 0;
+    int64_t comm_timeout_ms = 120000; // longest wait for a multi-GPU exchange before SFM_ERR_TIMEOUT (0 = for ever)
 };
 void sfm_ctx_retain(sfm_ctx *ctx);
 void sfm_ctx_release(sfm_ctx *ctx); // tears the context down when the last reference goes
@@ -155,6 +156,47 @@ struct PinBuf {
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// A reader on another stream (the multi-GPU gather runs on a stream of the communicator's) marks the point up to
+// which it reads an object's device buffers; the next call that overwrites them makes its stream wait for it.
+struct ReadFence {
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    hipError_t mark(hipStream_t reader)
+    {
+        if (!ev) {
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipEventRecord(ev, reader);
+        if (e == hipSuccess) pending = true;
+        return e;
+    }
+    hipError_t wait_on(hipStream_t writer)
+    {
+        if (!pending) return hipSuccess;
+        pending = false;
+        return hipStreamWaitEvent(writer, ev, 0);
+    }
+    void destroy()
+    {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+        pending = false;
+    }
+};
+
+// What the multi-GPU gather reads of a RANSAC batch after a run (device pointers; see sfm_ransac_gather).
+struct RansacGatherView {
+    sfm_ctx *ctx;
+    int n_pairs;
+    const int64_t *inlOff;  // [n_pairs + 1]
+    const int32_t *inliers; // CSR, ascending per pair
+    const void *packed;     // [n_pairs] records of SFM_RANSAC_RECORD_BYTES
+    ReadFence *fence;
+};
+#define SFM_RANSAC_RECORD_BYTES 120 // {int32 best row, count, iterations, pad; double error sum; double pose12[12]}
+int sfm_ransac_batch_gather_view(sfm_ransac_batch *b, RansacGatherView *v);
 
 // Event-pair timing of one kernel launch (on ctx->stream unless a stream is given).
 hipError_t sfm_span_begin(sfm_ctx *ctx, int which, hipStream_t st = nullptr);

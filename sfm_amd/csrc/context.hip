@@ -141,6 +141,9 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->ransac_mfma_ops_gib = (int)value;
     } else if (!strcmp(key, "ransac_seed")) {
         ctx->ransac_seed = (uint64_t)value;
+    } else if (!strcmp(key, "comm_timeout_ms")) {
+        if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "comm_timeout_ms must be >= 0");
+        ctx->comm_timeout_ms = value;
     } else if (!strcmp(key, "ransac_max_time_ms")) {
         if (value < 0) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac_max_time_ms must be >= 0");
         ctx->ransac_max_time_ms = value;

@@ -285,8 +285,16 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
     } else if (res->ctx != ctx) {
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "hamming: result belongs to another context");
     } else {
-        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream)); // staging buffers of a reused result
+        // The staging buffers of a reused result may still feed copies in flight, and a float call that used it
+        // before spreads its work over the context's three streams: wait for all of them.
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->stream2) SFM_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        if (ctx->stream3) SFM_HIP(ctx, hipStreamSynchronize(ctx->stream3));
     }
+    // This call uploads from the result's staging buffers on the context's stream and records no upload marker:
+    // the next call on this result, of either kind, waits for the streams instead of an event of an older call.
+    res->upValid = false;
+    SFM_HIP(ctx, res->readFence.wait_on(ctx->stream)); // a gather of the call before may still read the lists
     res->n_pairs = n_pairs;
     res->total = -1;
     hipStream_t st = ctx->stream;
@@ -437,5 +445,6 @@ extern "C" int sfm_match_batch_hamming(sfm_ctx *ctx, const sfm_binset *set, cons
                            (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
         SFM_HIP(ctx, hipGetLastError());
     }
-    return SFM_OK;
+    // the point on the context's stream where this call's lists are complete (the multi-GPU gather waits for it)
+    return sfm_match_result_mark_done(ctx, res);
 }

@@ -1705,6 +1705,7 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     (void)hipStreamSynchronize(r->ctx->stream2); // a call that failed half-way may have left work of this result there
     (void)hipStreamSynchronize(r->ctx->stream3);
     if (r->done) (void)hipEventDestroy(r->done);
+    r->readFence.destroy();
     if (r->upDone) (void)hipEventDestroy(r->upDone);
     if (r->statsEv) (void)hipEventDestroy(r->statsEv);
     r->hostStats.release();
@@ -1759,6 +1760,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         }
     }
     res->upValid = false;
+    // a gather of the call before may still read this result's lists on the communicator's stream
+    SFM_HIP(ctx, res->readFence.wait_on(ctx->stream));
     res->n_pairs = n_pairs;
     res->total = -1;
     sfm_span_reset(ctx, 0);
@@ -2242,7 +2245,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
 
 // The point on the context's stream where a batch call's lists are complete (the multi-GPU gather, which
 // runs on a stream of its own, waits for it).
-static int mark_done(sfm_ctx *ctx, sfm_match_result *res)
+int sfm_match_result_mark_done(sfm_ctx *ctx, sfm_match_result *res)
 {
     if (!res->done) SFM_HIP(ctx, hipEventCreateWithFlags(&res->done, hipEventDisableTiming));
     SFM_HIP(ctx, hipEventRecord(res->done, ctx->stream));
@@ -2255,7 +2258,7 @@ extern "C" int sfm_match_batch(sfm_ctx *ctx, const sfm_imageset *set, const int3
 {
     const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, metric, threshold, max_distance_px_squared,
                                     result_inout, false);
-    return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
+    return rc == SFM_OK ? sfm_match_result_mark_done(ctx, *result_inout) : rc;
 }
 
 extern "C" int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
@@ -2266,7 +2269,7 @@ extern "C" int sfm_match_batch_ratio(sfm_ctx *ctx, const sfm_imageset *set, cons
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1], was %g", (double)ratio);
     const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_COSINE, threshold, max_distance_px_squared,
                                     result_inout, false, ratio);
-    return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
+    return rc == SFM_OK ? sfm_match_result_mark_done(ctx, *result_inout) : rc;
 }
 
 extern "C" int sfm_match_batch_l2(sfm_ctx *ctx, const sfm_imageset *set, const int32_t *pair_list, int n_pairs,
@@ -2277,7 +2280,7 @@ extern "C" int sfm_match_batch_l2(sfm_ctx *ctx, const sfm_imageset *set, const i
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match: the ratio of the second-best test must lie in (0, 1] (0 = no test), was %g", (double)ratio);
     const int rc = match_batch_impl(ctx, set, pair_list, n_pairs, SFM_METRIC_L2, max_distance_squared, max_distance_px_squared,
                                     result_inout, false, ratio);
-    return rc == SFM_OK ? mark_done(ctx, *result_inout) : rc;
+    return rc == SFM_OK ? sfm_match_result_mark_done(ctx, *result_inout) : rc;
 }
 
 extern "C" int sfm_match_result_total(sfm_match_result *res, int64_t *total_out)

@@ -109,5 +109,7 @@ struct sfm_match_result {
     bool statsPending = false;
     PinBuf hostStats;
     hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
+    ReadFence readFence;       // a gather on another stream still reads offsets / pairs up to this point
 };
+int sfm_match_result_mark_done(sfm_ctx *ctx, sfm_match_result *res);
 

@@ -2406,6 +2406,7 @@ struct sfm_ransac_batch {
     bool scored = false;   // the last run went through selection (not fit-only)
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
     std::vector<int64_t> corrOffHost; // the last run's offsets
+    ReadFence readFence; // a gather on another stream still reads the winners' records and inlier lists up to this point
 };
 
 extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
@@ -2420,6 +2421,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     for (DevBuf *d : bufs) d->release();
     b->stage.release();
     b->stageIn.release();
+    b->readFence.destroy();
     sfm_ctx *owner = b->ctx;
     delete b;
     sfm_ctx_release(owner);
@@ -2485,6 +2487,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     } else if (b->ctx != ctx) {
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac: batch belongs to another context");
     }
+    SFM_HIP(ctx, b->readFence.wait_on(ctx->stream)); // a gather of the run before may still read its outputs
     b->n_pairs = n_pairs;
     b->H = n_hyp;
     b->total = total;
@@ -2754,6 +2757,21 @@ extern "C" int sfm_ransac_batch_refit(sfm_ransac_batch *b)
     hipLaunchKernelGGL(ransac_refit_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->args, rf);
     SFM_HIP(ctx, hipGetLastError());
     b->refitted = true;
+    return SFM_OK;
+}
+
+int sfm_ransac_batch_gather_view(sfm_ransac_batch *b, RansacGatherView *v)
+{
+    static_assert(sizeof(PackedBest) == SFM_RANSAC_RECORD_BYTES, "the gather moves the winners' records as they lie");
+    if (!b || !v) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    if (!b->scored) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "gather: the batch holds no RANSAC result");
+    v->ctx = ctx;
+    v->n_pairs = b->n_pairs;
+    v->inlOff = b->inlOff.as<int64_t>();
+    v->inliers = b->inliers.as<int32_t>();
+    v->packed = b->packed.p;
+    v->fence = &b->readFence;
     return SFM_OK;
 }
 

@@ -165,3 +165,38 @@ def test_gather_layout_against_numpy():
             for k, i in enumerate(o):
                 assert starts[i] == run and cnt[i] == counts[r, k]
                 run += counts[r, k]
+
+
+@pytest.mark.parametrize("n_pairs,world", [(1000, 8), (64 * 8 + 3, 8), (130, 2), (5, 4), (7, 1), (0, 3), (19900, 8)])
+def test_ransac_gather_unpack_against_numpy(n_pairs, world):
+    """sfm_shard_unpack_ransac: what the root does with the buffers of a RANSAC gather -- per rank the winners'
+    records (padded to the largest share) and, rank after rank, the inlier lists -- against per-pair results
+    dealt to the ranks in numpy and packed the way the ranks send them."""
+    from sfm_amd import capi
+    rng = np.random.default_rng(n_pairs + world)
+    counts_true = rng.integers(0, 40, n_pairs).astype(np.int32)
+    counts_true[rng.random(n_pairs) < 0.2] = 0
+    rec_true = np.zeros(n_pairs, capi.RANSAC_RECORD)
+    rec_true["best_h"] = np.where(counts_true > 0, rng.integers(0, 4096, n_pairs), -1)
+    rec_true["count"] = counts_true
+    rec_true["iterations"] = rng.integers(1, 4097, n_pairs)
+    rec_true["toterr"] = rng.random(n_pairs)
+    rec_true["pose12"] = rng.standard_normal((n_pairs, 12))
+    lists_true = [np.sort(rng.choice(20000, c, replace=False)).astype(np.int32) for c in counts_true]
+    owned = [capi.shard_indices(n_pairs, r, world) for r in range(world)]
+    max_owned = max(max(len(o) for o in owned), 1)
+    counts = np.zeros((world, max_owned), np.int32)
+    records = np.zeros((world, max_owned), capi.RANSAC_RECORD)
+    payload = []
+    for r, o in enumerate(owned):
+        counts[r, :len(o)] = counts_true[o]
+        records[r, :len(o)] = rec_true[o]
+        payload += [lists_true[i] for i in o]
+    payload = np.concatenate(payload) if payload else np.zeros(0, np.int32)
+    got = capi.shard_unpack_ransac(n_pairs, world, counts, records, payload)
+    assert np.array_equal(got["best_h"], rec_true["best_h"]) and np.array_equal(got["count"], counts_true)
+    assert np.array_equal(got["iterations"], rec_true["iterations"]) and np.array_equal(got["toterr"], rec_true["toterr"])
+    assert np.array_equal(got["pose12"], rec_true["pose12"])
+    assert np.array_equal(got["inlier_offsets"], np.concatenate([[0], np.cumsum(counts_true)]))
+    for i in range(n_pairs):
+        assert np.array_equal(got["inliers"][got["inlier_offsets"][i]:got["inlier_offsets"][i + 1]], lists_true[i])
