@@ -109,6 +109,12 @@ namespace SfM::solve
         if (!is_default(options)) return ransac_on_host(x, y, K, options, verbose);
 
         const auto start = std::chrono::steady_clock::now();
+        if (options.maxTimeMs <= 0) {
+            // RANSAC.cpp:189-196: the clock is read before the first iteration (i = 0), any time at all has passed
+            // by then, so a limit of zero or less stops the loop before a single row is fitted.
+            if (verbose) std::cout << "RANSAC: finished after 0 iterations (0ms)." << std::endl;
+            return {};
+        }
         sfm_ctx *ctx = sfm_amd_adaptor::context();
         const char *env = std::getenv("SFM_AMD_RANSAC_SEED");
         int rc = sfm_ctx_set_option(ctx, "ransac_seed", env ? static_cast<int64_t>(std::strtoull(env, nullptr, 10)) : 0);
@@ -117,15 +123,41 @@ namespace SfM::solve
         // Vec2 is two contiguous doubles (Eigen::Matrix<double, 2, 1>), so the vectors are double[2n]; Mat3 is
         // column-major, which is what the library takes.
         const int n = static_cast<int>(x.size());
+        const int rows = std::max(options.maxIter, 0);
         std::vector<int> inliers(x.size());
         int count = 0, iterations = 0;
         static_assert(sizeof(Vec2) == 2 * sizeof(double), "Vec2 must be two packed doubles");
-        rc = sfm_ransac_pair(ctx, x[0].data(), y[0].data(), n, K.data(), /*samples: drawn on the device*/ nullptr,
-                             std::max(options.maxIter, 0), options.minN, options.maxSquaredError, options.successProb, /*adaptive*/ 1,
-                             SFM_LOSS_REPROJECTION, inliers.data(), n, &count, nullptr, nullptr, nullptr, nullptr, &iterations);
+        // The reference reports every improvement of the kept model as it happens (RANSAC.cpp:251-254).  The device
+        // scans the rows itself; for a verbose call it also returns every row's inlier count and error sum (all rows
+        // are then scored in one go, so the time limit is not looked at during this call), and the lines are made
+        // from them below by the reference's own rule.
+        std::vector<int32_t> rowCount(verbose ? rows : 0);
+        std::vector<double> rowError(verbose ? rows : 0);
+        rc = sfm_ransac_pair(ctx, x[0].data(), y[0].data(), n, K.data(), /*samples: drawn on the device*/ nullptr, rows, options.minN,
+                             options.maxSquaredError, options.successProb, /*adaptive*/ 1, SFM_LOSS_REPROJECTION, inliers.data(), n,
+                             &count, nullptr, nullptr, verbose && rows ? rowCount.data() : nullptr,
+                             verbose && rows ? rowError.data() : nullptr, &iterations);
         if (rc != SFM_OK) sfm_amd_adaptor::fail(ctx, rc, "sfm_ransac_pair");
         inliers.resize(count);
-        if (verbose) // (the per-improvement lines of RANSAC.cpp:251-254 have no counterpart: the scan runs on the device)
+        if (verbose) {
+            int bestCount = 0, maxIter = options.maxIter;
+            REAL bestError = std::numeric_limits<REAL>::infinity();
+            for (int h = 0; h < iterations; h++) { // the rows an in-order loop visits before it stops
+                if (rowCount[h] <= 0) continue;
+                if (rowCount[h] > bestCount || (rowCount[h] == bestCount && rowError[h] < bestError)) {
+                    bestCount = rowCount[h];
+                    bestError = rowError[h];
+                    const REAL allInliers = std::pow(static_cast<REAL>(bestCount) / static_cast<REAL>(n), options.minN);
+                    if (allInliers >= EPSILON) {
+                        const int cap = safeCastToInt(std::ceil(std::log(1. - options.successProb) / std::log(1 - allInliers)));
+                        std::cout << "RANSAC: found better model with " << bestCount << " inliers that have a total error of " << bestError
+                                  << ", maxIter adjusted to " << std::min(cap, maxIter) << ".\n";
+                        if (cap < maxIter) maxIter = cap;
+                    }
+                }
+            }
+        }
+        if (verbose)
             std::cout << "RANSAC: finished after " << iterations << " iterations ("
                       << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start).count() << "ms)."
                       << std::endl;

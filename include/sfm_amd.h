@@ -293,11 +293,12 @@ int sfm_ransac_pair(sfm_ctx *ctx, const double *x, const double *y, int n, const
                     int *best_hyp_out, double *pose_out,
                     int32_t *counts_out, double *toterr_out, int *iterations_out);
 
-/* sfm_ransac_pair for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments,
- * same kernels, same results as sfm_ransac_pair, but all device work space is a fixed array that the
- * library's code object carries (about 3.4 MB per GPU, held until the process ends), so the call performs
- * no hipMalloc, no hipFree and creates no events.  Limits: n <= 16384 correspondences and
+/* sfm_ransac_pair for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc, code that holds a capture open on another stream).  No counterpart in the reference.
+ * Same arguments, same kernels, same results as sfm_ransac_pair, but all device work space is a fixed array
+ * that the library's code object carries (about 3.4 MB per GPU, held until the process ends), so the call
+ * performs no hipMalloc, no hipFree and creates no events.  It still copies from and to the caller's host
+ * arrays and waits for its stream before it returns, so it cannot itself be recorded into a graph.  Limits: n <= 16384 correspondences and
  * n_hyp <= 8192 sample rows; beyond them the call returns SFM_ERR_CAPACITY and does nothing.  All calls
  * on one GPU share that array: calls that overlap in time on one GPU (two contexts or two host threads)
  * race; successive calls are safe. */
@@ -314,10 +315,11 @@ int sfm_eight_point_fit(sfm_ctx *ctx, const double *x, const double *y, int n,
                         const int32_t *samples, int n_hyp, double *pose12_out);
 
 /* The whole of eightPointAlgorithmFromSubset (eightPoint.cpp:225-372): pose from the
- * n_calc = 8 sample correspondences, then every one of the n_all correspondences
- * triangulated under it (depth through float, :365).  pose16_out column-major
- * [R|T; 0 0 0 1], points_out[n_all][3]; either may be NULL.  n_calc < 8 ->
- * SFM_ERR_INVALID_ARG with the reference's message; n_calc > 8 -> SFM_ERR_UNSUPPORTED. */
+ * n_calc >= 8 sample correspondences (8: the 8x9 system of a RANSAC row; more:
+ * the n_calc x 9 system, solved as eightPointAlgorithm solves it), then every one
+ * of the n_all correspondences triangulated under it (depth through float, :365).
+ * pose16_out column-major [R|T; 0 0 0 1], points_out[n_all][3]; either may be
+ * NULL.  n_calc < 8 -> SFM_ERR_INVALID_ARG with the reference's message. */
 int sfm_eight_point_from_subset(sfm_ctx *ctx, const double *calc1, const double *calc2, int n_calc,
                                 const double *all1, const double *all2, int n_all,
                                 double *pose16_out, double *points_out);

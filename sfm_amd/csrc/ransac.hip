@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -2996,17 +2997,33 @@ extern "C" int sfm_eight_point_from_subset(sfm_ctx *ctx, const double *calc1, co
     if (n_calc < 8) // eightPoint.cpp:228-231
         SFM_FAIL(ctx, SFM_ERR_INVALID_ARG,
                  "EightPointFromSubset: There have to be at least 8 pair-to-pair-correspondences (was: %d) to approximate a pose.", n_calc);
-    if (n_calc != 8) SFM_FAIL(ctx, SFM_ERR_UNSUPPORTED, "EightPointFromSubset: the fit kernel takes exactly 8 correspondences (was: %d)", n_calc);
     if (!calc1 || !calc2 || n_all < 0 || (n_all > 0 && (!all1 || !all2))) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "EightPointFromSubset: null input");
-    const int64_t off[2] = {0, 8};
     const double K[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const int32_t rows[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-    int rc = ransac_run(ctx, 1, off, calc1, calc2, K, rows, 1, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, true, pair_batch(ctx));
-    if (rc != SFM_OK) return rc;
-    sfm_ransac_batch *b = *pair_batch(ctx);
-    hipStream_t st = ctx->stream;
     double pose12[12];
-    SFM_HIP(ctx, hipMemcpyAsync(pose12, b->pose12.p, sizeof pose12, hipMemcpyDeviceToHost, st));
+    hipStream_t st = ctx->stream;
+    sfm_ransac_batch *b = nullptr;
+    if (n_calc == 8) { // the fit kernel: one row of a sample table
+        const int64_t off[2] = {0, 8};
+        const int32_t rows[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+        int rc = ransac_run(ctx, 1, off, calc1, calc2, K, rows, 1, 0.0, 0.0, 0, SFM_LOSS_REPROJECTION, false, true, pair_batch(ctx));
+        if (rc != SFM_OK) return rc;
+        b = *pair_batch(ctx);
+        SFM_HIP(ctx, hipMemcpyAsync(pose12, b->pose12.p, sizeof pose12, hipMemcpyDeviceToHost, st));
+        if (!(n_all > 0 && points_out)) SFM_HIP(ctx, hipStreamSynchronize(st));
+    } else { // more than eight sample points: the n x 9 system, as eightPointAlgorithm solves it (eightPoint.cpp:233-344 is :64-185)
+        double pose16[16];
+        int rc = sfm_eight_point_algorithm(ctx, calc1, calc2, n_calc, pose16, nullptr);
+        if (rc != SFM_OK) return rc;
+        b = *pair_batch(ctx);
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) pose12[3 * r + c] = pose16[r + 4 * c];
+            pose12[9 + r] = pose16[r + 12];
+        }
+        if (n_all > 0 && points_out) {
+            SFM_HIP(ctx, b->pose12.reserve(sizeof pose12));
+            SFM_HIP(ctx, hipMemcpyAsync(b->pose12.p, pose12, sizeof pose12, hipMemcpyHostToDevice, st));
+        }
+    }
     if (n_all > 0 && points_out) { // the two point sets are staged behind each other in the (unused) error buffer
         SFM_HIP(ctx, b->errBuf.reserve((size_t)n_all * 2 * sizeof(double2)));
         SFM_HIP(ctx, b->refitPoints.reserve((size_t)n_all * 3 * sizeof(double)));
@@ -3017,8 +3034,8 @@ extern "C" int sfm_eight_point_from_subset(sfm_ctx *ctx, const double *calc1, co
                            b->refitPoints.as<double>());
         SFM_HIP(ctx, hipGetLastError());
         SFM_HIP(ctx, hipMemcpyAsync(points_out, b->refitPoints.p, (size_t)n_all * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        SFM_HIP(ctx, hipStreamSynchronize(st));
     }
-    SFM_HIP(ctx, hipStreamSynchronize(st));
     if (pose16_out) {
         for (int c = 0; c < 4; c++)
             for (int r = 0; r < 4; r++) pose16_out[r + 4 * c] = (r == c) ? 1.0 : 0.0;
@@ -3087,9 +3104,12 @@ static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 static unsigned char *g_scratchPtr[SFM_STATIC_MAX_DEVICES];
 static sfm_ransac_batch *g_staticBatch[SFM_STATIC_MAX_DEVICES];
 
+static std::mutex g_staticMutex; // contexts may be created from several host threads at once
+
 int sfm_ransac_static_setup(int device)
 {
     if (device < 0 || device >= SFM_STATIC_MAX_DEVICES) return SFM_OK; // such a device has no static entry point
+    std::lock_guard<std::mutex> lock(g_staticMutex);
     if (g_scratchPtr[device]) return SFM_OK;
     void *ptr = nullptr;
     if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return SFM_ERR_HIP;

@@ -195,10 +195,10 @@ int main(int argc, char **argv)
         return defaultLoss(Km, o1, o2, p, view);
     };
     auto inlPlug = solve::RANSAC(x, y, K, roPlug, false);
-    // a time limit of zero stops the device loop after its first slice of sample rows (RANSAC.cpp:189-196)
+    // a time limit of zero ends the loop before its first iteration (RANSAC.cpp:189-196): no inliers
     solve::RANSAC_OPTIONS roTime = ro;
     roTime.maxTimeMs = 0;
-    (void)solve::RANSAC(x, y, K, roTime, false);
+    if (!solve::RANSAC(x, y, K, roTime, false).empty()) return 8;
 
     // scene.cpp:264-298: refit on the inliers
     std::vector<Vec2> in1, in2;

@@ -67,6 +67,20 @@ def test_cpp_match_and_ransac(tmp_path, oracle):
     e = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
     assert np.array_equal(got["inliers"], e["inliers"])
     assert f"finished after {e['iterations']} iterations" in got["log"]
+    # the reference's line for every improvement of the kept model (RANSAC.cpp:251-254), replayed from the
+    # restatement's per-row counts and error sums
+    best_c, best_e, cap, lines = 0, np.inf, H, []
+    for h in range(e["iterations"]):
+        c, err = int(e["counts"][h]), float(e["toterr"][h])
+        if c > 0 and (c > best_c or (c == best_c and err < best_e)):
+            best_c, best_e = c, err
+            m = oracle.adaptive_max_iter(c, 1500, 8, 0.999)
+            if m >= 0:
+                lines.append(f"RANSAC: found better model with {c} inliers that have a total error of ")
+                lines.append(f", maxIter adjusted to {min(m, cap)}.")
+                cap = min(cap, m)
+    assert lines and all(l in got["log"] for l in lines)
+    assert got["log"].count("RANSAC: found better model") == len(lines) // 2
     assert len(got["inliers"]) > 100 and tv["inlier_mask"][got["inliers"]].mean() > 0.95
     again = run_case(tmp_path, dA, pA, dB, pB, 0.95, 1e4, tv, H, seed, "b")
     assert np.array_equal(got["inliers"], again["inliers"]) and np.array_equal(got["pairs"], again["pairs"])

@@ -560,3 +560,14 @@ def test_matrix_core_pretest_with_the_sampson_distance(ctx, oracle, ratio, thr, 
     exp = oracle.ransac(x, y, tv["K"], S, max_sq_err=thr, adaptive=False, loss_kind=capi.LOSS_SAMPSON)
     assert np.array_equal(res["mfma"]["counts"], exp["counts"]) and np.array_equal(res["mfma"]["inliers"], exp["inliers"])
     assert np.array_equal(res["mfma"]["toterr"].view(np.uint64), np.asarray(exp["toterr"]).view(np.uint64))
+
+
+@pytest.mark.parametrize("n_calc", [9, 12, 40, 300])
+def test_eight_point_from_subset_with_more_sample_points(ctx, oracle, n_calc):
+    """More than eight sample points (eightPoint.cpp:234-255 takes calcPoints1.size() rows): the pose is that of
+    the n x 9 system, every correspondence is triangulated under it."""
+    tv = synth.two_view(300, inlier_ratio=1.0, seed=23, noise_px=0.2)
+    pose, pts = ctx.eight_point_from_subset(tv["x"][:n_calc], tv["y"][:n_calc], tv["x"], tv["y"])
+    epose, epts, _, _ = oracle.eight_point_from_subset(tv["x"][:n_calc], tv["y"][:n_calc], tv["x"], tv["y"])
+    assert np.abs(pose - epose).max() < 1e-8
+    assert np.abs(pts - epts).max() <= 1e-6 * np.abs(epts).max()
