@@ -395,6 +395,24 @@ def test_32k_features_properties(ctx):
     s.close()
 
 
+@pytest.mark.parametrize("gate", [1e4, 1e8])
+def test_32k_pair_against_restatement(ctx, oracle, gate):
+    """One pair of the high-density configuration at full size (2 x 32768 features, 1.07e9 cells): pair list,
+    matches1 and matches2 equal those of matchTwoSided (match.cpp:24-94), whose restatement materialises the
+    4 GiB similarity matrix as the reference does; through the single-pair entry point and the batch one."""
+    n = 32768
+    d, p, c = synth.image_set(2, n, seed=78)
+    exp, e1, e2 = oracle.match(d[:n], p[:n], d[n:], p[n:], threshold=0.95, max_dist_sq=gate)
+    assert len(exp) > 5000
+    got, g1, g2 = ctx.match_pair(d[:n], p[:n], d[n:], p[n:], threshold=0.95, max_dist_sq=gate, return_best=True)
+    assert np.array_equal(g1, e1) and np.array_equal(g2, e2) and np.array_equal(got, exp)
+    s = ctx.imageset(c, d, p)
+    res = s.match(np.array([[0, 1]], np.int32), threshold=0.95, max_dist_sq=gate)
+    assert np.array_equal(res.pairs(), exp) and res.stats()[1] == 0
+    res.close()
+    s.close()
+
+
 def test_norm_square_root_is_correctly_rounded(ctx, oracle):
     """A descriptor matched with its copy at threshold 1.0: sim = n / (sqrtf(n) * sqrtf(n)) is 0.99999994 for
     this n (match.hpp:45), so the reference rejects it; a square root that is one ulp low would accept."""

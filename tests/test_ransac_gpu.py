@@ -571,3 +571,32 @@ def test_eight_point_from_subset_with_more_sample_points(ctx, oracle, n_calc):
     epose, epts, _, _ = oracle.eight_point_from_subset(tv["x"][:n_calc], tv["y"][:n_calc], tv["x"], tv["y"])
     assert np.abs(pose - epose).max() < 1e-8
     assert np.abs(pts - epts).max() <= 1e-6 * np.abs(epts).max()
+
+
+def test_stress_batch_against_restatement(ctx, oracle):
+    """The benchmark's RANSAC configuration as a batch: 64 pairs x 20 000 correspondences x 4096 sample rows,
+    15 % inliers, adaptive cap on, the matrix-core pre-test reading its prepared operand table -- the slicing,
+    the XCD placement and the table are the batch's own.  Four pairs sampled over the batch: winner, inlier
+    count, error sum, iterations, pose and inlier list equal those of the CPU restatement (RANSAC.cpp:213-258)
+    run on that pair alone."""
+    P, n, H = 64, 20000, 4096
+    xs, ys, Ss = [], [], []
+    for k in range(P):
+        tv = synth.two_view(n, inlier_ratio=0.15, seed=[3, k % 8])
+        xs.append(tv["x"]); ys.append(tv["y"])
+        Ss.append(synth.sample_table(n, H, seed=[4, k]))
+    K = synth.default_K()
+    off = np.arange(P + 1, dtype=np.int64) * n
+    b = ctx.ransac_batch(off, np.concatenate(xs), np.concatenate(ys), K, np.concatenate(Ss), H, max_sq_err=1.0,
+                         success_prob=0.999, adaptive=True)
+    best = b.best()
+    ioff, inl = b.inliers()
+    for k in (0, 21, 42, 63):
+        e = oracle.ransac(xs[k], ys[k], K, Ss[k], max_sq_err=1.0, success_prob=0.999, adaptive=True)
+        assert best["best_h"][k] == e["best_h"] and best["count"][k] == len(e["inliers"]), k
+        assert best["iterations"][k] == e["iterations"]
+        assert best["toterr"][k] == e["toterr"][e["best_h"]]
+        assert np.array_equal(inl[ioff[k]:ioff[k + 1]], e["inliers"])
+        pose12 = np.concatenate([e["pose"][:3, :3].reshape(-1), e["pose"][:3, 3]])
+        assert np.array_equal(best["pose12"][k].view(np.uint64), pose12.view(np.uint64))
+    b.close()
