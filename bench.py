@@ -41,6 +41,7 @@ RANSAC_BYTES_PER_PAIR = 1_082_368  # 20 000 corr * 32 B + 4096 hyp * (96 + 12) B
 # Vector-ALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles each, at the 2.4 GHz behind the
 # data sheet's vector figures (157.3 TFLOP/s fp32 = 1024 SIMDs x 16 lanes x 2 (packed) x 2 (fma) x 2.4 GHz).
 PEAK_VALU_GINST = 1024 * 2.4 / 4
+PEAK_FP64_TFLOPS = 78.6  # vector FP64, MI355X data sheet
 
 
 def main():
@@ -697,6 +698,25 @@ def ransac_valu_profile(mfma):
     return None, None, None, None
 
 
+def exact_path_profile():
+    """Vector instructions per wave and (hypothesis, correspondence) cell of the scoring kernel that evaluates
+    every cell (pre-test off), from the committed counter pass (static; None if the file is absent)."""
+    path = os.path.join(ROOT, "profiles", "r3_pmc_sq_ransac_exact_a.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    for k, v in t.items():
+        if isinstance(v, dict) and "ransac_score_kernel<0, false, false>" in k:
+            cells = v["SQ_WAVES"] * 20000.0  # the pass ran 128 pairs x 4096 rows x 20 000 correspondences
+            return {"valu_instructions_per_wave_and_cell": round(v["SQ_INSTS_VALU"] / cells, 1),
+                    "valu_busy_fraction_of_simd_cycles_under_counters": round(4.0 * v["SQ_INSTS_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8 * 1024), 4),
+                    "clock_GHz_under_counters": round(v["clock_GHz_under_load"], 3),
+                    "source": "static, not measured in this run: SQ_INSTS_VALU of scripts/pmc_ransac_regimes.sh 0.8 0 "
+                              "(profiles/r3_pmc_sq_ransac_exact_a.json) scaled to this run's cells"}
+    return None
+
+
 def bench_ransac(ctx, args, rank, world, dist, local_rank, comm=None):
     """hypotheses scored/s on one batch of ransac_pairs pairs/GPU x ransac_corr correspondences (15 % inliers)
     x ransac_hyps hypotheses, inputs resident on the device; at N = 1 also rows at inlier ratios where RANSAC
@@ -797,6 +817,7 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank, comm=None):
     out.update(gathered_info)
     if world == 1 and not args.no_regimes:
         rows = []
+        exact = exact_path_profile()
         for ratio in (0.5, 0.8):
             for filt in (1, 0):
                 el, kms, launches, best = measure(256, 64, ratio, False, filt, 1, 50 + int(ratio * 10))
@@ -807,6 +828,21 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank, comm=None):
                              "adaptive_stop": {"pairs_per_s": round(256 / el2, 1), "score_kernel_ms": round(kms2, 3),
                                                "mean_iterations": float(np.mean(best2["iterations"])),
                                                "mean_best_inliers": float(np.mean(best2["count"]))}})
+                if not filt and kms > 0:  # every cell evaluated exactly: the kernel's own roofline
+                    evals = 256.0 * H * n / (kms * 1e-3)
+                    rows[-1]["roofline"] = {
+                        "kernel": "ransac_score_kernel<0, false, false>", "evaluations_per_s": round(evals, 0),
+                        "fp64_flops_frac": round(evals * 92.0 / (PEAK_FP64_TFLOPS * 1e12), 4),
+                        "fp64_note": "92 algorithmic FP64 operations per evaluation against the 78.6 TFLOP/s vector peak: the "
+                                     "evaluation is ten IEEE divisions and four square roots deep, which cost an order of magnitude "
+                                     "more instructions than they count operations",
+                    }
+                    if exact:
+                        rate = evals / 64.0 * exact["valu_instructions_per_wave_and_cell"] / 1e9
+                        rows[-1]["roofline"].update({
+                            "bound": "valu issue", "achieved": round(rate, 1), "peak": PEAK_VALU_GINST, "unit": "G wave-instructions/s",
+                            "frac": round(rate / PEAK_VALU_GINST, 4)})
+                        rows[-1]["roofline"].update(exact)
         out["where_a_model_is_found"] = rows
         # extension (no counterpart in the reference): the Sampson distance as the loss, on the stress shape
         el, kms, launches, best = measure(512, 64, 0.15, True, 1, 1, 91, loss=1)

@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsfm_amd.so")
+LIB_PATH = os.environ.get("SFM_AMD_LIB") or os.path.join(_HERE, "lib", "libsfm_amd.so")  # (the variable: A/B runs of other builds)
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_HIP, ERR_TIMEOUT = range(8)
 METRIC_COSINE, METRIC_DOT, METRIC_L2 = 0, 1, 2

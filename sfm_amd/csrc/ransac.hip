@@ -28,7 +28,8 @@
 
 #define SCORE_CH 256 // correspondences staged in LDS per step
 #define SCORE_QCAP 16 // per-lane queue of correspondences awaiting exact evaluation
-#define REC_D 10     // doubles per prepared correspondence (9 used, padded to 80 bytes)
+#define REC_D 12     // doubles per prepared correspondence (11 used, padded to 96 bytes)
+#define REC_N 11     // of which make_record fills this many
 // The pre-test skips a cell whose estimated epipolar distance, less the margin that pays for the fp32
 // rounding, is at least this many times sqrt(maxSquaredError); a factor of sqrt(1.02) of it belongs to
 // that margin (see the scoring kernel), which leaves 1.052.
@@ -54,6 +55,7 @@ struct RansacArgs {
     int32_t *inliers;
     double K[9]; // column-major
     double Ki[4]; // pre-test constants (valid when filter != 0): 1/fx, 1/fy, 1/min(fx,fy), max(fx,fy)^2
+    int plainK;   // 1: K = [fx 0 cx; 0 fy cy; 0 0 1] with finite entries (lets an evaluation skip the camera-1 error, see reprojection_loss)
     int filter;   // 1: the epipolar pre-test of the scoring kernel may be used
     int mfma;     // 1: unsplit launches run the pre-test on the matrix cores (ransac_score_mfma_kernel)
     int mfKe;     // and scale the hypothesis side of num by 2^mfKe
@@ -126,16 +128,16 @@ __device__ __forceinline__ void householder_make(double c0, double t1, double t2
     }
 }
 
-__device__ __forceinline__ Qr32 qr32_factor(const double a[3], double x2, double y2, double bb)
+// n1 = sqrt(bb) is passed in: it belongs to the correspondence, callers hoist it out of their loops over poses.
+__device__ __forceinline__ Qr32 qr32_factor(const double a[3], double x2, double y2, double n1in)
 {
     const double eps = 2.220446049250313e-16;
     Qr32 F;
     double p0 = -a[0], p1 = -a[1], p2 = -a[2];
     double q0 = x2, q1 = y2, q2 = 1.0;
     const double n0 = sqrt((p0 * p0 + p1 * p1) + p2 * p2);
-    double n1 = sqrt(bb);
+    double n1 = n1in;
     const double maxn = (n1 > n0) ? n1 : n0;
-    const double threshold_helper = ((maxn * eps) * (maxn * eps)) / 3.0;
     F.pivots = 2;
     F.swapped = n1 > n0;
     if (F.swapped) {
@@ -152,16 +154,25 @@ __device__ __forceinline__ Qr32 qr32_factor(const double a[3], double x2, double
         q1 = q1 - tmp * (F.tau0 * F.e01);
         q2 = q2 - tmp * (F.tau0 * F.e02);
     }
+    // The remaining column's norm, downdated.  Eigen multiplies temp by (updated norm / directly computed norm)^2;
+    // both are n1 at this point, and x / x is exactly 1 for every finite non-zero x (for an infinite or NaN n1 the
+    // factor is NaN and the comparison it feeds is false), so the division is left out.
     double upd = n1;
     if (upd != 0.0) {
         double temp = fabs(q0) / upd;
         temp = (1.0 + temp) * (1.0 - temp);
         temp = temp < 0.0 ? 0.0 : temp;
-        const double temp2 = temp * ((upd / n1) * (upd / n1));
-        if (temp2 <= 1.4901161193847656e-08) upd = sqrt(q1 * q1 + q2 * q2);
-        else upd = upd * sqrt(temp);
+        const bool direct = (n1 - n1 == 0.0) && temp <= 1.4901161193847656e-08; // (a NaN factor fails the comparison)
+        upd = direct ? sqrt(q1 * q1 + q2 * q2) : upd * sqrt(temp);
     }
-    if (upd * upd < threshold_helper * 2.0) F.pivots = 1;
+    // The second pivot counts unless upd^2 < 2 (maxn eps)^2 / 3.  That threshold is ~3.3e-32 maxn^2: unless upd^2 is
+    // below 4e-32 maxn^2 (which the exact threshold cannot exceed, roundings included) the answer is known without
+    // the threshold's division.
+    const double u2 = upd * upd;
+    if (u2 < (maxn * maxn) * 4e-32) {
+        const double threshold_helper = ((maxn * eps) * (maxn * eps)) / 3.0;
+        if (u2 < threshold_helper * 2.0) F.pivots = 1;
+    }
     double unused;
     householder_make(q1, q2, 0.0, false, F.beta1, F.tau1, F.e11, unused);
     F.r01 = q0;
@@ -196,45 +207,76 @@ __device__ __forceinline__ void qr32_solve(const Qr32 &F, const double T[3], dou
     l1 = F.swapped ? c0 : s1;
 }
 
-__device__ __forceinline__ void triangulate_lambdas(const double a[3], double x2, double y2, double bb,
+__device__ __forceinline__ void triangulate_lambdas(const double a[3], double x2, double y2, double n1,
                                                     const double T[3], double &l0, double &l1)
 {
-    const Qr32 F = qr32_factor(a, x2, y2, bb);
+    const Qr32 F = qr32_factor(a, x2, y2, n1);
     qr32_solve(F, T, l0, l1);
 }
 
-// Default loss (solve.hpp:119-124) of one prepared correspondence under pose (R, T).
-__device__ __forceinline__ double reprojection_loss(const double *K, const Pose &P, double x1, double y1,
-                                                    double x2, double y2, double bb, double o1x, double o1y,
-                                                    double o2x, double o2y)
+// B1 of reprojection_loss: what the camera-1 error of a correspondence cannot exceed, or inf.
+__device__ __forceinline__ double loss1_bound(const double *K, int plainK, double x1, double y1)
 {
+    const double sx = (fabs(K[0] * x1) + fabs(K[3] * y1)) + fabs(K[6]);
+    const double sy = (fabs(K[1] * x1) + fabs(K[4] * y1)) + fabs(K[7]);
+    const bool ordinary = plainK && fabs(x1) <= 1e6 && fabs(y1) <= 1e6 && sx <= 1e18 && sy <= 1e18;
+    return ordinary ? (70.0 * 1.232595164407831e-32) * (sx * sx + sy * sy) : INFINITY; // 70 * 2^-106
+}
+
+// Default loss (solve.hpp:119-124) of one prepared correspondence (a record of make_record) under pose (R, T),
+// or +inf where the correspondence is shown not to be an inlier (error >= thr, or NaN) without finishing it.
+// Two shortcuts, neither of which changes a value that is used:
+//   * the loss is max(loss1, loss2) by std::max's rule, (loss1 < loss2) ? loss2 : loss1.  If loss2 >= thr the
+//     result is loss2, or a loss1 that is not below loss2 (NaN included): not below thr in any case, so the
+//     camera-1 error is never looked at;
+//   * the triangulated point lies on the ray of the first observation by construction, so loss1 is rounding
+//     noise: with K = [fx 0 cx; 0 fy cy; 0 0 1], a finite non-zero depth and ordinary coordinates the third
+//     row of K pt is the depth itself, every one of the eight operations behind each of its two terms is off
+//     by at most 2^-53 relatively, and loss1 <= 66.1 2^-106 (Sx^2 + Sy^2) with Sx = |fx x1| + |0 y1| + |cx|, Sy
+//     likewise.  The record carries B1 = 70 2^-106 (Sx^2 + Sy^2) (inf where the conditions fail); a finite loss2
+//     at or above it is the maximum, whatever loss1 is exactly.
+// STAGED: r is a prepared record (make_record: both observations in pixels, B1 and the norm of the second ray
+// come with it).  Otherwise r = {x1, y1, x2, y2} and everything else is made from them where it is needed, with
+// the same expressions: an evaluation that is one of a few survivors of the pre-test then keeps four values
+// alive across the factorisation instead of eleven.
+template <bool STAGED>
+__device__ __forceinline__ double reprojection_loss(const double *K, int plainK, double thr, const Pose &P, const double *r)
+{
+    const double x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
     double a[3];
     rot_apply_h(P.R, x1, y1, a);
     double l0, l1;
-    triangulate_lambdas(a, x2, y2, bb, P.T, l0, l1);
+    triangulate_lambdas(a, x2, y2, STAGED ? r[10] : sqrt((x2 * x2 + y2 * y2) + 1.0), P.T, l0, l1);
     const float lambda1 = (float)l0; // eightPoint.cpp:365
     const double l = (double)lambda1;
     const double pt0 = l * x1, pt1 = l * y1, pt2 = l;
-    // camera 1, view = identity (solve.hpp:121)
-    double p0 = (K[0] * pt0 + K[3] * pt1) + K[6] * pt2;
-    double p1 = (K[1] * pt0 + K[4] * pt1) + K[7] * pt2;
-    double p2 = (K[2] * pt0 + K[5] * pt1) + K[8] * pt2;
-    p0 = p0 / p2;
-    p1 = p1 / p2;
-    double dx = p0 - o1x, dy = p1 - o1y;
-    const double loss1 = dx * dx + dy * dy;
     // camera 2, view = [R|T] (solve.hpp:122)
     const double q0 = ((P.R[0][0] * pt0 + P.R[0][1] * pt1) + P.R[0][2] * pt2) + P.T[0];
     const double q1 = ((P.R[1][0] * pt0 + P.R[1][1] * pt1) + P.R[1][2] * pt2) + P.T[1];
     const double q2 = ((P.R[2][0] * pt0 + P.R[2][1] * pt1) + P.R[2][2] * pt2) + P.T[2];
-    p0 = (K[0] * q0 + K[3] * q1) + K[6] * q2;
-    p1 = (K[1] * q0 + K[4] * q1) + K[7] * q2;
-    p2 = (K[2] * q0 + K[5] * q1) + K[8] * q2;
+    double p0 = (K[0] * q0 + K[3] * q1) + K[6] * q2;
+    double p1 = (K[1] * q0 + K[4] * q1) + K[7] * q2;
+    double p2 = (K[2] * q0 + K[5] * q1) + K[8] * q2;
     p0 = p0 / p2;
     p1 = p1 / p2;
-    dx = p0 - o2x;
-    dy = p1 - o2y;
+    const double o2x = STAGED ? r[7] : (K[0] * x2 + K[3] * y2) + K[6]; // solve.hpp:91
+    const double o2y = STAGED ? r[8] : (K[1] * x2 + K[4] * y2) + K[7];
+    double dx = p0 - o2x, dy = p1 - o2y;
     const double loss2 = dx * dx + dy * dy;
+    if (loss2 >= thr) return INFINITY;
+    const double B1 = STAGED ? r[9] : loss1_bound(K, plainK, x1, y1);
+    if (loss2 >= B1 && l != 0.0 && fabs(l) < INFINITY) return loss2;
+    // camera 1, view = identity (solve.hpp:121)
+    p0 = (K[0] * pt0 + K[3] * pt1) + K[6] * pt2;
+    p1 = (K[1] * pt0 + K[4] * pt1) + K[7] * pt2;
+    p2 = (K[2] * pt0 + K[5] * pt1) + K[8] * pt2;
+    p0 = p0 / p2;
+    p1 = p1 / p2;
+    const double o1x = STAGED ? r[5] : (K[0] * x1 + K[3] * y1) + K[6];
+    const double o1y = STAGED ? r[6] : (K[1] * x1 + K[4] * y1) + K[7];
+    dx = p0 - o1x;
+    dy = p1 - o1y;
+    const double loss1 = dx * dx + dy * dy;
     return (loss1 < loss2) ? loss2 : loss1; // std::max(loss1, loss2)
 }
 
@@ -273,7 +315,7 @@ __host__ __device__ inline size_t rec32_start(int64_t base, int p) { return (siz
 // The values of a correspondence that the reference recomputes per hypothesis: both observations, x2h.x2h,
 // and obs = K * (ox, oy, 1) for both (solve.hpp:90-91).  With the pre-test on they are made where they are
 // needed (the rare exact evaluations) instead of being stored: 80 bytes per correspondence less to write.
-__device__ __forceinline__ void make_record(const RansacArgs &g, int64_t at, double r[9])
+__device__ __forceinline__ void make_record(const RansacArgs &g, int64_t at, double r[REC_N])
 {
     const double2 a = g.x[at], b = g.y[at];
     r[0] = a.x;
@@ -285,6 +327,8 @@ __device__ __forceinline__ void make_record(const RansacArgs &g, int64_t at, dou
     r[6] = (g.K[1] * a.x + g.K[4] * a.y) + g.K[7];
     r[7] = (g.K[0] * b.x + g.K[3] * b.y) + g.K[6];
     r[8] = (g.K[1] * b.x + g.K[4] * b.y) + g.K[7];
+    r[9] = loss1_bound(g.K, g.plainK, a.x, a.y);
+    r[10] = sqrt(r[4]); // the norm of the second observation's ray: the second column of every 3x2 system of this correspondence
 }
 
 __device__ __forceinline__ double mfma_margin(const RansacArgs &g, double x1n2, double x2n2, double amax);
@@ -298,14 +342,14 @@ __global__ __launch_bounds__(256) void ransac_prep_kernel(const RansacArgs g, in
     if (!g.filter) { // the instances without the pre-test stage these records in LDS
         double *dst = g.rec + k * REC_D;
 #pragma unroll
-        for (int i = 0; i < 9; i++) dst[i] = r[i];
-        dst[9] = 0.0;
+        for (int i = 0; i < REC_N; i++) dst[i] = r[i];
+        dst[REC_N] = 0.0;
         if (!g.mfma) return; // (Sampson distance: unsplit launches run the matrix-core test, split ones the instances above)
     }
     // x1h.x1h for the scoring kernel's pre-test, or +inf for a correspondence it must not skip
     const double big = 1e6;
     const bool tame = fabs(r[5]) <= big && fabs(r[6]) <= big && fabs(r[7]) <= big && fabs(r[8]) <= big;
-    r[9] = tame ? (r[0] * r[0] + r[1] * r[1]) + 1.0 : INFINITY;
+    r[9] = tame ? (r[0] * r[0] + r[1] * r[1]) + 1.0 : INFINITY; // (from here on r[9] is the pre-test's, not B1)
     // fp32 record of the pre-test: x1, y1, fx x2 / c, fy y2 / c (the observation in pixels off the centre, in
     // units of the skip distance c = SKIP_FACTOR sqrt(maxSquaredError)) and the margin G that pays for the
     // rounding of the fp32 estimate (derived in the scoring kernel), or inf.  Correspondences 4j .. 4j + 3 of a
@@ -715,13 +759,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int cnt[4] = {0, 0, 0, 0};
     for (int i = 0; i < 8; i++) {
         const double2 a = g.x[base + idx[i]], b = g.y[base + idx[i]];
-        const double bb = (b.x * b.x + b.y * b.y) + 1.0;
+        const double nb = sqrt((b.x * b.x + b.y * b.y) + 1.0);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             double av[3];
             rot_apply_h(r ? R2 : R1, a.x, a.y, av);
             double l0, l1;
-            triangulate_lambdas(av, b.x, b.y, bb, T12, l0, l1);
+            triangulate_lambdas(av, b.x, b.y, nb, T12, l0, l1);
             if (l0 > 0 && l1 > 0) cnt[2 * r]++;
             if (-l0 > 0 && -l1 > 0) cnt[2 * r + 1]++;
         }
@@ -852,10 +896,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
     // (the pre-test instance queues indices relative to the pair, kChunk staying 0 for record(), and makes
     // the fp64 record from the observations in global memory; the others index the chunk staged in LDS)
     auto evaluate = [&](int kk) {
-        double made[9];
-        if (FILTER) make_record(g, base + kk, made);
-        const double *r = FILTER ? made : rec + kk * REC_D;
-        record(kk, reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]));
+        if constexpr (FILTER) { // a survivor of the pre-test: its two observations from global memory
+            const double2 o1 = g.x[base + kk], o2 = g.y[base + kk];
+            const double xy[4] = {o1.x, o1.y, o2.x, o2.y};
+            record(kk, reprojection_loss<false>(K, g.plainK, thr, P, xy));
+        } else {
+            record(kk, reprojection_loss<true>(K, g.plainK, thr, P, rec + kk * REC_D));
+        }
     };
     auto drain = [&]() {
         for (int i = 0; __builtin_amdgcn_ballot_w64(i < npend) != 0; i++)
@@ -886,9 +933,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
             const int row = (int)blockIdx.x * 256 + wave * 64 + (int)poolL[POOL ? wave : 0][POOL ? at : 0]; // relative to hBegin
             Pose Q;
             load_pose(g.pose12 + ((size_t)p * g.H + g.hBegin + row) * 12, Q);
-            double r[9];
-            make_record(g, base + k, r);
-            const double e = reprojection_loss(K, Q, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            const double2 o1 = g.x[base + k], o2 = g.y[base + k];
+            const double xy[4] = {o1.x, o1.y, o2.x, o2.y};
+            const double e = reprojection_loss<false>(K, g.plainK, thr, Q, xy);
             errBuf[((size_t)base + k) * rows + row] = (e < thr) ? e : none;
         }
         poolCount -= take;
@@ -1322,14 +1369,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
             hl = (int)(ent >> 24);
             Pose Q;
             load_pose(poseP + (size_t)(rowW0 + hl) * 12, Q);
-            double r[9];
-            make_record(g, base + k, r);
+            const double2 o1 = g.x[base + k], o2 = g.y[base + k];
+            const double xy[4] = {o1.x, o1.y, o2.x, o2.y};
             if constexpr (LOSS == SFM_LOSS_SAMPSON) {
                 double E[3][3];
                 essential_from_pose(Q, E);
-                e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+                e = sampson_loss(K, E, xy[0], xy[1], xy[2], xy[3]);
             } else {
-                e = reprojection_loss(K, Q, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+                e = reprojection_loss<false>(K, g.plainK, thr, Q, xy);
             }
             inl = e < thr; // RANSAC.cpp:216
         }
@@ -1351,13 +1398,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
             for (int i = 0; i < T / 4; i++) {
                 unsigned long long mk = accM[i * 64 + lane];
                 if (mk) accM[i * 64 + lane] = 0ull;
+                // Four entries per round: their errors are fetched from LDS together and then added in order (a
+                // fetch per addition left the chain waiting on LDS for every entry).  Where fewer than four are
+                // left the chain adds -0.0, which changes no sum.
                 while (__builtin_amdgcn_ballot_w64(mk != 0ull) != 0) {
-                    if (mk) {
-                        const int l = __builtin_ctzll(mk);
-                        mk &= mk - 1;
-                        count[i]++;
-                        tot[i] += accE[l];
+                    double ev[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool has = mk != 0ull;
+                        const int l = has ? __builtin_ctzll(mk) : 0;
+                        mk &= mk - 1ull;
+                        const double v = accE[l];
+                        ev[j] = has ? v : -0.0;
+                        count[i] += has ? 1 : 0;
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) tot[i] += ev[j];
                 }
             }
         }
@@ -1740,16 +1796,15 @@ __global__ __launch_bounds__(256) void ransac_inlier_flag_kernel(const RansacArg
         double K[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) K[i] = g.K[i];
-        double made[9];
-        if (g.filter) make_record(g, base + k, made);
-        const double *r = g.filter ? made : g.rec + (base + k) * REC_D;
+        const double2 o1 = g.x[base + k], o2 = g.y[base + k];
+        const double xy[4] = {o1.x, o1.y, o2.x, o2.y};
         double e;
         if (g.loss == SFM_LOSS_SAMPSON) {
             double E[3][3];
             essential_from_pose(P, E);
-            e = sampson_loss(K, E, r[0], r[1], r[2], r[3]);
+            e = sampson_loss(K, E, xy[0], xy[1], xy[2], xy[3]);
         } else {
-            e = reprojection_loss(K, P, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8]);
+            e = reprojection_loss<false>(K, g.plainK, g.maxSqErr, P, xy);
         }
         ok = e < g.maxSqErr;
     }
@@ -2286,13 +2341,13 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
     for (int k = tid; k < n; k += 256) {
         const int64_t at = base + (useInl ? list[k] : k);
         const double2 a = g.x[at], b = g.y[at];
-        const double bb = (b.x * b.x + b.y * b.y) + 1.0;
+        const double nb = sqrt((b.x * b.x + b.y * b.y) + 1.0);
 #pragma unroll
         for (int r = 0; r < 2; r++) { // candidates 2r, 2r + 1: same rotation, opposite translations
             double av[3];
             rot_apply_h(Rc[r], a.x, a.y, av);
             double l0, l1;
-            triangulate_lambdas(av, b.x, b.y, bb, T12, l0, l1);
+            triangulate_lambdas(av, b.x, b.y, nb, T12, l0, l1);
             if (l0 > 0 && l1 > 0) cnt[2 * r]++;
             if (-l0 > 0 && -l1 > 0) cnt[2 * r + 1]++;
         }
@@ -2334,11 +2389,11 @@ __global__ __launch_bounds__(256) void ransac_refit_kernel(const RansacArgs g, c
     for (int k = tid; k < n; k += 256) {
         const int64_t at = base + (useInl ? list[k] : k);
         const double2 a = g.x[at], b = g.y[at];
-        const double bb = (b.x * b.x + b.y * b.y) + 1.0;
+        const double nb = sqrt((b.x * b.x + b.y * b.y) + 1.0);
         double av[3];
         rot_apply_h(Rc[ci >> 1], a.x, a.y, av);
         double l0, l1;
-        triangulate_lambdas(av, b.x, b.y, bb, Tc, l0, l1);
+        triangulate_lambdas(av, b.x, b.y, nb, Tc, l0, l1);
         const double lam = (double)(float)l0; // eightPoint.cpp:216
         pts[3 * k + 0] = lam * a.x;
         pts[3 * k + 1] = lam * a.y;
@@ -2361,7 +2416,7 @@ __global__ __launch_bounds__(256) void ransac_triangulate_kernel(const double *_
     double av[3];
     rot_apply_h(P.R, a.x, a.y, av);
     double l0, l1;
-    triangulate_lambdas(av, b.x, b.y, (b.x * b.x + b.y * b.y) + 1.0, P.T, l0, l1);
+    triangulate_lambdas(av, b.x, b.y, sqrt((b.x * b.x + b.y * b.y) + 1.0), P.T, l0, l1);
     const double lam = (double)(float)l0;
     points[3 * k + 0] = lam * a.x;
     points[3 * k + 1] = lam * a.y;
@@ -2582,6 +2637,11 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.inlOff = b->inlOff.as<int64_t>();
     g.inliers = b->inliers.as<int32_t>();
     for (int i = 0; i < 9; i++) g.K[i] = K[i];
+    {
+        bool finite = true;
+        for (int i = 0; i < 9; i++) finite = finite && std::isfinite(K[i]) && std::fabs(K[i]) <= 1e12;
+        g.plainK = (finite && K[1] == 0.0 && K[2] == 0.0 && K[3] == 0.0 && K[5] == 0.0 && K[8] == 1.0) ? 1 : 0;
+    }
     bool sampsonTest = false;
     {
         // K column-major: K(r,c) = K[r + 3c].  The pre-test needs K = [fx 0 cx; 0 fy cy; 0 0 1] with
