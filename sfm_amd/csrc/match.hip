@@ -1159,6 +1159,18 @@ __global__ __launch_bounds__(256) void match_flood_probe_kernel(const MatchArgs 
     }
 }
 
+// In place of an int8 strict pass that is known to flood (see the chunk loop): every pair with work gets the flag
+// such a pass would have left.
+__global__ __launch_bounds__(256) void match_flag_flooded_kernel(const MatchArgs g, int np)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= np) return;
+    const PairRec pr = g.pairs[p];
+    if (pr.nA <= 0 || pr.nB <= 0) return;
+    g.pairOvf[p] = 3;
+    if (g.flagCount[3] == 0) g.flagCount[3] = 1; // (only zero / non-zero matters)
+}
+
 // One work item per block: the pass every pair takes.
 template <int OCC, int FORM, bool DOT, bool GENERAL, int ABL>
 __global__ __launch_bounds__(SIM_WAVES * 64, OCC) void match_sim_kernel(const MatchArgs g)
@@ -1790,10 +1802,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             }
         } else {
             res->candObserved = 0;
+            res->floodObserved = false;
             probing = true;
         }
     } else {
         res->candObserved = 0;
+        res->floodObserved = false;
     }
     memset(&res->observedFor, 0, sizeof res->observedFor);
     res->observedFor = key;
@@ -2022,7 +2036,12 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         int fullest = 0;
         bool gaveUp = false; // a pair went to the cell-by-cell pass: the maximum was not enough for it
         for (size_t k = 0; k < nCount; k++) fullest = std::max(fullest, seen[k]);
-        for (int k = 0; k < np; k++) gaveUp = gaveUp || seen[nCount + k] == 2;
+        int flooded = 0; // pairs whose int8 lists overflowed and that the fp16 strict pass did not settle either
+        for (int k = 0; k < np; k++) {
+            gaveUp = gaveUp || seen[nCount + k] == 2;
+            flooded += (seen[nCount + k] == 1 || seen[nCount + k] == 2) ? 1 : 0;
+        }
+        res->floodObserved = np >= 16 && 10 * flooded >= 9 * np;
         int64_t slice = 64;
         while (slice < 2 * (int64_t)fullest + 64) slice *= 2;
         candCap = gaveUp ? candCapMax : (int)std::min<int64_t>(candCapMax, slice * maxQueues);
@@ -2099,10 +2118,18 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             const bool cosine = metric != SFM_METRIC_DOT; // the L2 mode runs the cosine bound passes with its own per-pair bound
             const bool strictFirst = cosine || dotStrict;  // (the dot metric too, under a cosine bound from the images' largest norms)
             bool forked = false;
+            // A loose threshold (the reference's default, match.hpp:59) floods the int8 lists of every pair, and the
+            // attempt is wasted: when nine pairs in ten of the observed first chunk ended in the filtered passes, the
+            // later chunks (and later calls with the same options) start where a flooded int8 pass would leave them
+            // -- every pair flagged for the probe below, which still decides pair by pair between the fp16 strict
+            // pass and the filtered ones.  A wrong guess costs time only: all paths give the same lists.
+            const bool skipInt8 = res->floodObserved && !probe && variant.strict16 && ctx->match_flood_probe &&
+                                  metric == SFM_METRIC_COSINE && ratio == 0.0f;
             if (strictFirst) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
-                hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
+                if (skipInt8) hipLaunchKernelGGL(match_flag_flooded_kernel, dim3((np + 255) / 256), dim3(256), 0, st, g, np);
+                else hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
                 SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
                 // The first bound passes of consecutive chunks follow each other on this stream (each fills the
                 // device on its own, and their timing spans stay clean); everything else of the chunk, the passes

@@ -101,6 +101,7 @@ struct sfm_match_result {
     DevBuf rowMax;           // two-phase filtered passes: a float per row of a chunk (per buffer set)
     DevBuf candProbe;        // lists of the first chunk of a call that observes how far they fill
     int candObserved = 0;    // candidate slots per pair sized from such a first chunk (0 = none yet)
+    bool floodObserved = false; // in that first chunk nine pairs in ten flooded their int8 lists and went on to the filtered passes
     MatchKey observedFor = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};
     size_t packedBytes = 0; // single-pair calls: bytes of m1 before the list (count, per-row and per-column bests)
     hipEvent_t upDone = nullptr;  // the last upload of the last batch call from hostRecs / hostWork has been made

@@ -577,6 +577,41 @@ def test_flood_probe_changes_nothing(ctx, oracle):
             assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2), (thr, probe)
 
 
+def test_later_chunks_skip_an_int8_pass_that_floods(ctx, oracle):
+    """A call of several chunks at the reference's default threshold (match.hpp:59): the observed first chunk floods
+    its int8 lists, so the later chunks skip that pass and start from the flood probe -- including pairs that would
+    not have flooded (tiny images, images of duplicates the threshold keeps apart), which then take the fp16 strict
+    pass.  A second call on the same result object skips it from the first chunk on.  Lists equal the restatement's
+    for every pair, and equal a run in one chunk."""
+    counts = np.array([1100, 1100, 1100, 1100, 1100, 1100, 1100, 40, 300], np.int32)
+    n = 1100
+    d, p, _ = synth.image_set(len(counts), n, shared_frac=0.4, seed=123)
+    desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)])
+    pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)])
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    big = synth.exhaustive_pairs(7)                       # 21 pairs of full images: the observed chunk
+    rest = np.array([[i, j] for i in range(9) for j in (7, 8) if i != j] + [[k, k] for k in range(7)], np.int32)
+    pl = np.concatenate([big, rest, big[::-1]]).astype(np.int32)
+    s = ctx.imageset(counts, desc, pts)
+    ctx.set_option("pairs_per_launch", 21)
+    try:
+        res = s.match(pl, threshold=0.5, max_dist_sq=1e8)
+        off, pairs = res.offsets(), res.pairs()
+        again = s.match(pl, threshold=0.5, max_dist_sq=1e8, result=res)   # the observation is kept with the result
+        assert np.array_equal(again.offsets(), off) and np.array_equal(again.pairs(), pairs)
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+    one = s.match(pl, threshold=0.5, max_dist_sq=1e8)
+    assert np.array_equal(one.offsets(), off) and np.array_equal(one.pairs(), pairs)
+    for k in list(range(0, len(pl), 5)) + [21, 22, 23, len(pl) - 1]:
+        a, b = pl[k]
+        exp, _, _ = oracle.match(desc[starts[a]:starts[a + 1]], pts[starts[a]:starts[a + 1]],
+                                 desc[starts[b]:starts[b + 1]], pts[starts[b]:starts[b + 1]], threshold=0.5, max_dist_sq=1e8)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp), k
+    for o in (res, one, s):
+        o.close()
+
+
 @pytest.mark.parametrize("spread", [0.0, 0.2])
 def test_dot_metric_through_the_strict_passes(ctx, oracle, spread):
     """dotProduct (match.hpp:18-27) on descriptors of unit or nearly unit norm: a.b > T implies a cosine above
