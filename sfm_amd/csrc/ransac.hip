@@ -60,6 +60,14 @@ struct RansacArgs {
     int mfma;     // 1: unsplit launches run the pre-test on the matrix cores (ransac_score_mfma_kernel)
     int mfKe;     // and scale the hypothesis side of num by 2^mfKe
     double mfI[2]; // that test's 1/fx, 1/fy: the camera's for the reprojection loss, 2/(fx + fy) twice for the Sampson distance
+    // rows with many inliers, handed over for evaluation cell by cell (see ransac_heavy_find_kernel)
+    unsigned int *heavyCount; // [0]: candidates found in this slice, [1]: slots claimed (both may run past their limits: claims beyond were refused)
+    long long *candRow;       // [candMax] pair << 32 | row
+    unsigned int *candUb;     // [candMax] cells of the row that pass the packed test: an upper bound of its count
+    long long *heavyRow;      // [heavyMax] pair << 32 | row of the slot
+    double *heavyErr;         // [heavyMax][heavyStride] error of the cell where it is an inlier's, else -1
+    int candMax, heavyMax, heavyStride;
+    int heavyBound;           // 1: candUb is made for this slice, and rows whose bound is below the pair's best count are passed over
     uint4 *mfOps; // the correspondence side of that test, made once per call (see mfma_ops_start), or NULL: the
                   // scoring kernel makes it from the fp32 records as it goes
     double maxSqErr;
@@ -77,6 +85,14 @@ struct RansacArgs {
     const unsigned long long *t0;
     long long maxTicks; // 0 = no cap
 };
+
+// Last row (exclusive) of pair p in the current phase.  After the first phase a pair's scan has an iteration cap
+// (RANSAC.cpp:245-258) that can only fall: rows at or past it are never reached by the in-order loop, so they are
+// neither fitted nor scored, whatever the phase's common end is.
+__device__ __forceinline__ int pair_row_end(const RansacArgs &g, int p)
+{
+    return (g.hBegin > 0 && g.adaptive) ? min(g.hEnd, g.maxIter[p]) : g.hEnd;
+}
 
 // ---------------------------------------------------------------------------------------
 // shared device math (mirrors the CPU restatement's evaluation order)
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int h = g.hBegin + blockIdx.x * 64 + threadIdx.x;
     const int64_t base = g.corrOff[p];
     const int64_t n = g.corrOff[p + 1] - base;
-    if (h >= g.hEnd || n < 8 || !g.active[p]) return;
+    if (n < 8 || !g.active[p] || h >= pair_row_end(g, p)) return;
     const int32_t *s = g.samples + ((size_t)p * g.H + h) * 8;
     int idx[8];
     bool valid = true;
@@ -848,7 +864,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
     const int64_t base = g.corrOff[p];
     const int n = (int)(g.corrOff[p + 1] - base);
     if (!g.active[p]) return; // the pair's scan stopped in an earlier phase
-    const bool active = h < g.hEnd;
+    const int rowEnd = pair_row_end(g, p);
+    if (g.hBegin + (int)blockIdx.x * 256 >= rowEnd) return; // rows the scan cannot reach (the whole block)
+    const bool active = h < rowEnd;
     int kBeg = 0, kEnd = n;
     if (SPLIT) {
         const int seg = (((n + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3; // whole groups of the fp32 records
@@ -859,7 +877,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FILTER && !
     const int rows = g.hEnd - g.hBegin;
     double *errCol = SPLIT ? errBuf + (size_t)base * rows + (h - g.hBegin) : nullptr; // + k * rows
     // a slice of fewer than 256 rows leaves whole waves without a row: they only help staging
-    const bool waveIdle = SPLIT && g.hBegin + (int)blockIdx.x * 256 + (tid & ~63) >= g.hEnd;
+    const bool waveIdle = SPLIT && g.hBegin + (int)blockIdx.x * 256 + (tid & ~63) >= rowEnd;
     Pose P;
     load_pose(g.pose12 + ((size_t)p * g.H + (active ? h : 0)) * 12, P);
     double E[3][3];
@@ -1263,29 +1281,68 @@ __global__ __launch_bounds__(256) void ransac_mfma_ops_kernel(const RansacArgs g
     }
 }
 
-template <int T, bool PRE, int LOSS = SFM_LOSS_REPROJECTION>
+#ifdef SFM_DEBUG_WAVES // measurement build only: cells evaluated, waves and their running times (100 MHz ticks), per launch
+__device__ unsigned long long g_waveStat[8];
+extern "C" int sfm_debug_wave_stats(unsigned long long *out)
+{
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_waveStat), sizeof(unsigned long long) * 8);
+    unsigned long long zero[8] = {0};
+    if (rc == 0) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_waveStat), zero, sizeof zero);
+    return rc;
+}
+#endif
+// DEFER: rows with many inliers hold a wave up -- their cells are evaluated 64 at a time by a wave whose other
+// rows have long been done, and at the end of a launch a few such waves keep the device waiting.  Such rows are
+// dealt with beforehand (ransac_heavy_find_kernel and the kernels after it) and marked in the count array:
+// ROW_HANDED rows are evaluated cell by cell after this kernel (ransac_heavy_eval_kernel, ransac_heavy_sum_kernel),
+// ROW_PASSED rows cannot matter to the scan and stay at count 0.  Neither gets operands here, so none of their
+// cells passes the test; the sums of ROW_HANDED rows are not written.
+#define DEFER_CHECK_STEPS 64 // steps of 16 correspondences over which ransac_heavy_find_kernel counts
+#define DEFER_SHARE_FIRST 8  // a row is a candidate when more than one in this many of those cells pass the test: first slice,
+#define DEFER_SHARE_LATER 32 // and later slices when a bound can be had (most candidates are then passed over)
+#define ROW_HANDED (-1)
+#define ROW_PASSED (-2)
+// Pairs whose best model so far holds few of their correspondences are not searched for such rows after the first
+// slice (no such row has shown yet, and the search would cost more than it saves).
+__device__ __forceinline__ bool defer_applies(const RansacArgs &g, int p, int n)
+{
+    if (g.heavyMax <= 0 || n < 16 * 4 * DEFER_CHECK_STEPS) return false;
+    return g.hBegin == 0 || (long long)g.bestCount[p] * DEFER_SHARE_FIRST >= n;
+}
+template <int T, bool PRE, int LOSS = SFM_LOSS_REPROJECTION, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ransac_score_mfma_kernel(const RansacArgs g)
 {
+    // A wave takes 16 T rows (T tiles of the matrix cores) through all correspondences of its pair.  T = 4 reads
+    // the correspondence side once per 64 rows; T = 1 and 2 read it four times and twice as often but make four
+    // times and twice as many waves of a slice of rows, each with a quarter and a half of the work: they are
+    // for slices that would leave most of the device idle otherwise, where a wave's running time decides.
     constexpr int ROWS_W = 16 * T, ROWS_B = 4 * ROWS_W;
-    static_assert(T == 4, "a lane owns T / 4 rows of its wave; eight tiles per wave (three waves per SIMD) measured slower");
+    static_assert(T == 1 || T == 2 || T == 4, "lane l keeps the sums of row l of its wave; eight tiles per wave (three waves per SIMD) measured slower");
+    constexpr int OWN = 1; // rows whose sums a lane keeps
     // One drain site per step: the queue must take what a step can add (every cell of the wave's T tiles) on
     // top of what a drain leaves (< 64).
     constexpr int QCAP = 64 + T * 256;
     constexpr int OPB_HALVES = 2 * MF_CH * 32; // num side, then q side
-    constexpr int SLICE_HALVES = 4 * 64 * 64;  // the hypothesis operands on their way into fragments
+    constexpr int SLICE_HALVES = 4 * 64 * 64;  // the hypothesis operands on their way into fragments (64 x 64 halves per wave)
     // per wave, behind the queues: the errors of the 64 entries of a drain, and per row of the wave the lanes
     // whose entries are inliers of that row (one bit per lane)
-    constexpr int ACC_BYTES = 64 * 8 + ROWS_W * 8;
-    constexpr int ACC_AT = OPB_HALVES * 2 + 4 * QCAP * 4;
+    constexpr int ACC_BYTES = 64 * 8 + 64 * 8;
+    constexpr int FRONT = (PRE ? 0 : OPB_HALVES * 2); // the staged correspondence side, when the blocks make it
+    constexpr int ACC_AT0 = FRONT + 4 * QCAP * 4;
+    constexpr int ACC_AT = ACC_AT0 >= SLICE_HALVES * 2 ? ACC_AT0 : SLICE_HALVES * 2;
     static_assert(ACC_AT >= SLICE_HALVES * 2 && ACC_AT % 8 == 0, "the row masks are cleared before the set-up uses its slices");
     constexpr int SMEM_BYTES = ACC_AT + 4 * ACC_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     _Float16 *opB = reinterpret_cast<_Float16 *>(smem);
-    unsigned int *pool = reinterpret_cast<unsigned int *>(smem + OPB_HALVES * 2) + (threadIdx.x >> 6) * QCAP;
+    unsigned int *pool = reinterpret_cast<unsigned int *>(smem + FRONT) + (threadIdx.x >> 6) * QCAP;
     double *accE = reinterpret_cast<double *>(smem + ACC_AT + (threadIdx.x >> 6) * ACC_BYTES);
     unsigned long long *accM = reinterpret_cast<unsigned long long *>(accE + 64);
-#pragma unroll
-    for (int i = 0; i < T / 4; i++) accM[i * 64 + (threadIdx.x & 63)] = 0ull;
+    accM[threadIdx.x & 63] = 0ull;
+#ifdef SFM_DEBUG_WAVES
+    const unsigned long long dbgT0 = wall_clock64();
+    unsigned long long dbgEvals = 0, dbgDrains = 0, dbgSecond = 0;
+    (void)dbgSecond;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
     // Blocks go to the eight XCDs in turn.  All row blocks of a pair run on one of them (same residue mod 8),
@@ -1308,48 +1365,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
     const int64_t base = g.corrOff[p];
     const int n = (int)(g.corrOff[p + 1] - base);
     if (!g.active[p]) return;
+    const int rowEnd = pair_row_end(g, p);
+    if (g.hBegin + rowBlock * ROWS_B >= rowEnd) return; // rows the scan cannot reach (the whole block)
     const int rowW0 = g.hBegin + rowBlock * ROWS_B + wave * ROWS_W; // the wave's first row
-    const int nRowsW = max(0, min(ROWS_W, g.hEnd - rowW0));
+    const int nRowsW = max(0, min(ROWS_W, rowEnd - rowW0));
     const double *poseP = g.pose12 + (size_t)p * g.H * 12;
     double K[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) K[i] = g.K[i];
     const double thr = g.maxSqErr;
 
+    // (DEFER) the row whose sums this lane keeps (row `lane` of the wave) was handed over, or is passed over
+    bool ownHanded = false, ownPassed = false;
+    if constexpr (DEFER) {
+        if (defer_applies(g, p, n) && lane < nRowsW) {
+            const int mark = g.counts[(size_t)p * g.H + rowW0 + lane];
+            ownHanded = mark == ROW_HANDED;
+            ownPassed = mark == ROW_PASSED;
+        }
+    }
     // hypothesis operands: every lane makes those of one row, the wave's slice of LDS turns them into fragments
     half8 An[T], Aq[T];
     {
         _Float16 *slice = opB + wave * (64 * 64);
+        const bool valid = lane < nRowsW && !ownHanded && !ownPassed;
+        Pose P;
+        load_pose(poseP + (size_t)(valid ? rowW0 + lane : g.hBegin) * 12, P);
+        _Float16 ops[64];
+        mfma_hyp_operands(g, P, valid, ops);
+        __syncthreads();
 #pragma unroll
-        for (int round = 0; round < T / 4; round++) {
-            const int hl = round * 64 + lane;
-            const bool valid = hl < nRowsW;
-            Pose P;
-            load_pose(poseP + (size_t)(valid ? rowW0 + hl : g.hBegin) * 12, P);
-            _Float16 ops[64];
-            mfma_hyp_operands(g, P, valid, ops);
-            __syncthreads();
+        for (int v = 0; v < 8; v++) {
+            half8 w;
 #pragma unroll
-            for (int v = 0; v < 8; v++) {
-                half8 w;
+            for (int i = 0; i < 8; i++) w[i] = ops[8 * v + i];
+            *reinterpret_cast<half8 *>(slice + lane * 64 + 8 * v) = w;
+        }
+        __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 8; i++) w[i] = ops[8 * v + i];
-                *reinterpret_cast<half8 *>(slice + lane * 64 + 8 * v) = w;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int tt = 0; tt < 4; tt++) {
-                An[4 * round + tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + quad * 8);
-                Aq[4 * round + tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + 32 + quad * 8);
-            }
+        for (int tt = 0; tt < T; tt++) {
+            An[tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + quad * 8);
+            Aq[tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + 32 + quad * 8);
         }
         __syncthreads();
     }
 
-    int count[T / 4];
-    double tot[T / 4];
+    int count[OWN];
+    double tot[OWN];
 #pragma unroll
-    for (int i = 0; i < T / 4; i++) {
+    for (int i = 0; i < OWN; i++) {
         count[i] = 0;
         tot[i] = 0.0;
     }
@@ -1361,6 +1425,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         int hl = 0;
         double e = 0.0;
         bool inl = false;
+#ifdef SFM_DEBUG_WAVES
+        dbgEvals += take;
+        dbgDrains++;
+#endif
         if (lane < take) {
             int at = qHead + lane;
             if (at >= QCAP) at -= QCAP;
@@ -1395,7 +1463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int i = 0; i < T / 4; i++) {
+            for (int i = 0; i < OWN; i++) {
                 unsigned long long mk = accM[i * 64 + lane];
                 if (mk) accM[i * 64 + lane] = 0ull;
                 // Four entries per round: their errors are fetched from LDS together and then added in order (a
@@ -1537,13 +1605,329 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         }
     }
     if (qCount > 0) drain(qCount);
+#ifdef SFM_DEBUG_WAVES
+    if (lane == 0 && nRowsW > 0) {
+        const unsigned long long dt = wall_clock64() - dbgT0;
+        atomicAdd(&g_waveStat[0], dbgEvals);
+        atomicAdd(&g_waveStat[1], dt);
+        atomicMax(&g_waveStat[2], dt);
+        atomicAdd(&g_waveStat[3], 1ull);
+        atomicAdd(&g_waveStat[4], dbgDrains);
+        atomicAdd(&g_waveStat[5], dbgSecond);
+        atomicMax(&g_waveStat[6], dbgEvals);
+    }
+#endif
 #pragma unroll
-    for (int i = 0; i < T / 4; i++) {
+    for (int i = 0; i < OWN; i++) {
         const int hl = i * 64 + lane;
-        if (hl < nRowsW) {
+        if (hl < nRowsW && !ownHanded) {
             g.counts[(size_t)p * g.H + rowW0 + hl] = count[i];
             g.toterr[(size_t)p * g.H + rowW0 + hl] = tot[i];
         }
+    }
+}
+
+// Finds the candidates, before ransac_score_mfma_kernel<.., DEFER> runs with the same grid: a wave runs the
+// matrix-core test of its 64 rows over the pair's first 16 DEFER_CHECK_STEPS correspondences and only counts, per
+// row, the cells that pass.  A row with more than one in DEFER_SHARE_* enters the candidate list; every row of
+// the slice is marked 0 (ransac_heavy_assign_kernel marks the candidates it settles).
+__global__ __launch_bounds__(256) void ransac_heavy_find_kernel(const RansacArgs g)
+{
+    constexpr int T = 4, ROWS_W = 64, ROWS_B = 256;
+    __shared__ __attribute__((aligned(16))) _Float16 opB[4 * 64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    int p, rowBlock;
+    { // the same placement as the scoring kernel's
+        const int gx = (g.hEnd - g.hBegin + ROWS_B - 1) / ROWS_B, L = (int)blockIdx.x;
+        const int full = (g.nPairs >> 3) << 3;
+        if (L < full * gx) {
+            const int grp = L / (8 * gx), l = L - grp * 8 * gx;
+            p = grp * 8 + (l & 7);
+            rowBlock = l >> 3;
+        } else {
+            const int l = L - full * gx;
+            p = full + l / gx;
+            rowBlock = l - (l / gx) * gx;
+        }
+    }
+    const int64_t base = g.corrOff[p];
+    const int n = (int)(g.corrOff[p + 1] - base);
+    if (!g.active[p] || !defer_applies(g, p, n)) return;
+    const int rowEnd = pair_row_end(g, p);
+    if (g.hBegin + rowBlock * ROWS_B >= rowEnd) return;
+    const int rowW0 = g.hBegin + rowBlock * ROWS_B + wave * ROWS_W;
+    const int nRowsW = max(0, min(ROWS_W, rowEnd - rowW0));
+    half8 An[T], Aq[T];
+    {
+        _Float16 *slice = opB + wave * (64 * 64);
+        const bool valid = lane < nRowsW;
+        Pose P;
+        load_pose(g.pose12 + ((size_t)p * g.H + (valid ? rowW0 + lane : g.hBegin)) * 12, P);
+        _Float16 ops[64];
+        mfma_hyp_operands(g, P, valid, ops);
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            half8 w;
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = ops[8 * v + i];
+            *reinterpret_cast<half8 *>(slice + lane * 64 + 8 * v) = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int tt = 0; tt < T; tt++) {
+            An[tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + quad * 8);
+            Aq[tt] = *reinterpret_cast<const half8 *>(slice + (tt * 16 + col) * 64 + 32 + quad * 8);
+        }
+    }
+    if (nRowsW <= 0) return;
+    int ub[T][4]; // cells of the lane's column that passed, per row 16 t + 4 quad + r
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) ub[t][r] = 0;
+    const floatx4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const half8 *opsL = reinterpret_cast<const half8 *>(g.mfOps + mfma_ops_start(base, p) * 128) + lane;
+    half8 bn = opsL[0], bq = opsL[64];
+    for (int s = 0; s < DEFER_CHECK_STEPS; s++) {
+        const half8 *opN = opsL + (size_t)min(s + 1, DEFER_CHECK_STEPS - 1) * 128;
+        const half8 bn2 = opN[0], bq2 = opN[64];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const floatx4 nu = __builtin_amdgcn_mfma_f32_16x16x32_f16(An[t], bn, zero, 0, 0, 0);
+            const floatx4 qq = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aq[t], bq, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) ub[t][r] += __builtin_fmaf(nu[r], nu[r], qq[r]) < 0.0f ? 1 : 0;
+        }
+        bn = bn2;
+        bq = bq2;
+    }
+    // Lane (quad, col) speaks for row 16 (col >> 2) + 4 quad + (col & 3) of the wave: its cells are spread over the
+    // 16 lanes of the quad, counted under index [col >> 2][col & 3].
+    int mine = 0;
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int c = ub[t][r];
+            c += __shfl_xor(c, 1);
+            c += __shfl_xor(c, 2);
+            c += __shfl_xor(c, 4);
+            c += __shfl_xor(c, 8);
+            if (col == 4 * t + r) mine = c;
+        }
+    const int spokenRow = (col >> 2) * 16 + quad * 4 + (col & 3);
+    const bool inPlay = spokenRow < nRowsW;
+    const int share = g.heavyBound ? DEFER_SHARE_LATER : DEFER_SHARE_FIRST;
+    const bool heavy = inPlay && mine * share >= 16 * DEFER_CHECK_STEPS;
+    const unsigned long long want = __builtin_amdgcn_ballot_w64(heavy);
+    if (want != 0ull) {
+        const int first = __builtin_ctzll(want);
+        unsigned at = 0;
+        if (lane == first) at = atomicAdd(&g.heavyCount[0], (unsigned)__builtin_popcountll(want));
+        at = __builtin_amdgcn_readlane(at, first);
+        const unsigned mineAt = at + __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        if (heavy && mineAt < (unsigned)g.candMax) { // (a candidate beyond the list's end stays with the scoring kernel)
+            g.candRow[mineAt] = ((long long)p << 32) | (long long)(unsigned)(rowW0 + spokenRow);
+            g.candUb[mineAt] = 0u;
+        }
+    }
+    if (inPlay) g.counts[(size_t)p * g.H + rowW0 + spokenRow] = 0;
+}
+
+// The cells of a candidate row that pass the packed fp32 test of ransac_score_kernel (a cell that fails it lies
+// too far from its epipolar line to be an inlier): their number bounds the row's count from above.  A block
+// per candidate, in turn.
+__global__ __launch_bounds__(256) void ransac_heavy_bound_kernel(const RansacArgs g)
+{
+    __shared__ unsigned int part[4];
+    const int cands = (int)min(g.heavyCount[0], (unsigned)g.candMax);
+    const double skipDist = SKIP_FACTOR * sqrt(g.maxSqErr);
+    for (int c = blockIdx.x; c < cands; c += gridDim.x) {
+        const long long hr = g.candRow[c];
+        const int p = (int)(hr >> 32), row = (int)(hr & 0xFFFFFFFFll);
+        const int64_t base = g.corrOff[p];
+        const int n = (int)(g.corrOff[p + 1] - base);
+        Pose Q;
+        load_pose(g.pose12 + ((size_t)p * g.H + row) * 12, Q);
+        double E[3][3];
+        essential_from_pose(Q, E);
+        float Ef[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Ef[i] = (float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] * skipDist : (i < 6 ? g.Ki[1] * skipDist : 1.0)));
+        const float *rec = g.rec32 + rec32_start(base, p);
+        unsigned int cnt = 0;
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const float *grp = rec + (size_t)(k >> 2) * 20 + (k & 3);
+            const float x1 = grp[0], y1 = grp[4], u2 = grp[8], v2 = grp[12], gg = grp[16];
+            const float m0 = __builtin_fmaf(Ef[0], x1, __builtin_fmaf(Ef[1], y1, Ef[2]));
+            const float m1 = __builtin_fmaf(Ef[3], x1, __builtin_fmaf(Ef[4], y1, Ef[5]));
+            const float m2 = __builtin_fmaf(Ef[6], x1, __builtin_fmaf(Ef[7], y1, Ef[8]));
+            const float num = __builtin_fmaf(u2, m0, __builtin_fmaf(v2, m1, m2));
+            const float q = __builtin_fmaf(m0, m0, __builtin_fmaf(m1, m1, gg));
+            cnt += !(num * num >= q) ? 1u : 0u; // (a NaN passes)
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) g.candUb[c] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
+    }
+}
+
+// Settles the candidates, a thread each.  A candidate whose bound is below the count of the pair's best model so
+// far can neither replace it (RANSAC.cpp:224, more inliers or as many with a smaller error sum) nor lower the
+// iteration cap (:245-258): the in-order scan passes over it whatever its exact count is, so it is marked
+// ROW_PASSED and none of its cells is evaluated.  The others claim a slot of the error buffer and are marked
+// ROW_HANDED; where no slot is left the row keeps its mark of 0 and the scoring kernel takes it.
+__global__ __launch_bounds__(256) void ransac_heavy_assign_kernel(const RansacArgs g)
+{
+    const int cands = (int)min(g.heavyCount[0], (unsigned)g.candMax);
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cands; c += gridDim.x * 256) {
+        const long long hr = g.candRow[c];
+        const int p = (int)(hr >> 32), row = (int)(hr & 0xFFFFFFFFll);
+        int mark = 0;
+        if (g.heavyBound && g.candUb[c] < (unsigned)g.bestCount[p]) {
+            mark = ROW_PASSED;
+        } else {
+            const unsigned slot = atomicAdd(&g.heavyCount[1], 1u);
+            if (slot < (unsigned)g.heavyMax) {
+                g.heavyRow[slot] = hr;
+                mark = ROW_HANDED;
+            }
+        }
+        if (mark) g.counts[(size_t)p * g.H + row] = mark;
+    }
+}
+
+// The rows handed over, cell by cell: a block takes 256 correspondences of one such row, a lane one cell (the
+// row's pose is the same for the whole block).  Every lane works, whatever the row's share of inliers, and the
+// blocks are as many as the device holds, each taking (slot, chunk) items in turn.
+template <int LOSS>
+__global__ __launch_bounds__(256) void ransac_heavy_eval_kernel(const RansacArgs g)
+{
+    const int used = (int)min(g.heavyCount[1], (unsigned)g.heavyMax);
+    const int chunks = g.heavyStride / 256;
+    double K[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = g.K[i];
+    const double thr = g.maxSqErr;
+    for (long long item = blockIdx.x; item < (long long)used * chunks; item += gridDim.x) {
+        const int slot = (int)(item / chunks), chunk = (int)(item - (long long)slot * chunks);
+        const long long hr = g.heavyRow[slot];
+        const int p = (int)(hr >> 32), row = (int)(hr & 0xFFFFFFFFll);
+        const int64_t base = g.corrOff[p];
+        const int n = (int)(g.corrOff[p + 1] - base);
+        if (chunk * 256 >= n) continue;
+        const int k = chunk * 256 + (int)threadIdx.x;
+        double e = -1.0;
+        if (k < n) {
+            Pose Q;
+            load_pose(g.pose12 + ((size_t)p * g.H + row) * 12, Q);
+            const double2 o1 = g.x[base + k], o2 = g.y[base + k];
+            const double xy[4] = {o1.x, o1.y, o2.x, o2.y};
+            if constexpr (LOSS == SFM_LOSS_SAMPSON) {
+                double E[3][3];
+                essential_from_pose(Q, E);
+                e = sampson_loss(K, E, xy[0], xy[1], xy[2], xy[3]);
+            } else {
+                e = reprojection_loss<false>(K, g.plainK, thr, Q, xy);
+            }
+            if (!(e < thr)) e = -1.0; // RANSAC.cpp:216
+        }
+        g.heavyErr[(size_t)slot * g.heavyStride + k] = e;
+    }
+}
+
+// Count and error sum of the rows handed over, in correspondence order (RANSAC.cpp:207-221): 64 rows per block,
+// all waves bring tiles of 64 correspondences x 64 rows into LDS, the first wave adds a tile up, a lane per
+// row, while the next one is on its way (a cell that is no inlier adds -0.0, which changes no sum).
+__global__ __launch_bounds__(256) void ransac_heavy_sum_kernel(const RansacArgs g)
+{
+    __shared__ double tile[2][64][65];
+    __shared__ int sN[64], sP[64], sRow[64];
+    const int used = (int)min(g.heavyCount[1], (unsigned)g.heavyMax);
+    const int slot0 = blockIdx.x * 64;
+    if (slot0 >= used) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        const int slot = slot0 + tid;
+        int n = 0, p = -1, row = 0;
+        if (slot < used) {
+            const long long hr = g.heavyRow[slot];
+            p = (int)(hr >> 32);
+            row = (int)(hr & 0xFFFFFFFFll);
+            n = (int)(g.corrOff[p + 1] - g.corrOff[p]);
+        }
+        sN[tid] = n;
+        sP[tid] = p;
+        sRow[tid] = row;
+    }
+    __syncthreads();
+    int nMax = 0;
+    for (int i = 0; i < 64; i++) nMax = max(nMax, sN[i]);
+    int myN[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) myN[j] = sN[wave * 16 + j];
+    const double *src = g.heavyErr + (size_t)(slot0 + wave * 16) * g.heavyStride + lane;
+    double regs[16];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) regs[j] = (k0 + lane < myN[j]) ? src[(size_t)j * g.heavyStride + k0] : -1.0;
+    };
+    // Only the additions of a row depend on each other.  Telling inliers from the rest and counting them is done by
+    // the threads that fetch: a cell that is no inlier goes into the tile as -0.0, so the chain is one LDS read and
+    // one addition per cell.
+    __shared__ int cnts[64];
+    if (tid < 64) cnts[tid] = 0;
+    int cnt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) cnt[j] = 0;
+    double tot = 0.0;
+    fetch(0);
+    int b = 0;
+    for (int k0 = 0; k0 < nMax; k0 += 64, b ^= 1) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const bool in = regs[j] >= 0.0;
+            tile[b][lane][wave * 16 + j] = in ? regs[j] : -0.0;
+            cnt[j] += in ? 1 : 0;
+        }
+        __syncthreads();
+        if (k0 + 64 < nMax) fetch(k0 + 64);
+        if (wave == 0) { // sixteen cells are on their way from LDS while the sixteen before them are added
+            double v[16], w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = tile[b][i][lane];
+#pragma unroll
+            for (int kk = 0; kk < 64; kk += 32) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) w[i] = tile[b][kk + 16 + i][lane];
+#pragma unroll
+                for (int i = 0; i < 16; i++) tot = tot + v[i];
+                if (kk + 32 < 64) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = tile[b][kk + 32 + i][lane];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) tot = tot + w[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) { // the wave's lanes hold 64 correspondences' worth of row wave * 16 + j
+        int c = cnt[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        if (lane == 0) cnts[wave * 16 + j] = c;
+    }
+    __syncthreads();
+    if (wave == 0 && sP[lane] >= 0) {
+        g.counts[(size_t)sP[lane] * g.H + sRow[lane]] = cnts[lane];
+        g.toterr[(size_t)sP[lane] * g.H + sRow[lane]] = tot;
     }
 }
 
@@ -1568,8 +1952,9 @@ __global__ __launch_bounds__(SUM_THREADS) void ransac_sum_kernel(const RansacArg
     const int64_t base = g.corrOff[p];
     const int n = (int)(g.corrOff[p + 1] - base);
     const int rows = g.hEnd - g.hBegin;
+    if (g.hBegin + (int)blockIdx.x * R >= pair_row_end(g, p)) return; // rows nobody scored (the whole block)
     const int hl = blockIdx.x * R + r;
-    const bool live = hl < rows;
+    const bool live = g.hBegin + hl < pair_row_end(g, p);
     const double *col = errBuf + (size_t)base * rows + (live ? hl : 0);
     const double none = __longlong_as_double(-1ll);
     constexpr int DEPTH = 2; // tiles in flight (four measured the same: the additions, not the fetches, set the pace)
@@ -1690,7 +2075,9 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
         best = g.bestH[p];
         bestError = g.bestErr[p];
     }
-    const int rows = g.hEnd - g.hBegin;
+    // (rows at or past the cap the phase began with were not scored: the scan cannot reach them)
+    const int hEnd = (g.hBegin > 0 && g.adaptive) ? min(g.hEnd, capIn) : g.hEnd;
+    const int rows = max(hEnd - g.hBegin, 0);
     const int seg = (rows + 255) / 256;
     const int q0 = g.hBegin + min(rows, tid * seg), q1 = g.hBegin + min(rows, (tid + 1) * seg);
     const int *cnt = g.counts + (size_t)p * g.H;
@@ -1700,7 +2087,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
     int local = 0;
     for (int q = q0; q < q1; q++) local = max(local, cnt[q]);
     sMax[tid] = local;
-    if (tid == 0) sStop = g.hEnd;
+    if (tid == 0) sStop = hEnd;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
         const int v = (tid >= d) ? sMax[tid - d] : 0;
@@ -1769,7 +2156,7 @@ __global__ __launch_bounds__(256) void ransac_select_kernel(const RansacArgs g)
         // the scan goes on iff it consumed this phase without reaching its cap and rows remain, and the
         // caller's time is not up (the reference looks at the clock every 50 iterations and stops the loop)
         const bool timeUp = g.maxTicks > 0 && (long long)(wall_clock64() - *g.t0) > g.maxTicks;
-        g.active[p] = (stop == g.hEnd && stop < capOut && g.hEnd < g.H && !timeUp) ? 1 : 0;
+        g.active[p] = (stop == g.hEnd && stop < capOut && g.hEnd < g.H && !timeUp) ? 1 : 0; // (stop < g.hEnd where the cap cut the phase short)
     }
 }
 
@@ -2455,7 +2842,8 @@ struct sfm_ransac_batch {
     int H = 0;
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
-        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, mfOps, inlFlag, inlBlk, clock, packed;
+        inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, mfOps, inlFlag, inlBlk, clock, packed,
+        heavyCount, heavyRow, heavyErr, candRow, candUb;
     PinBuf stage;   // single-pair calls: the winner's record and its inlier list in one copy
     PinBuf stageIn; // and the two correspondence arrays on their way in
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
@@ -2473,7 +2861,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
                       &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->mfOps, &b->inlFlag, &b->inlBlk,
-                      &b->clock, &b->packed};
+                      &b->clock, &b->packed, &b->heavyCount, &b->heavyRow, &b->heavyErr, &b->candRow, &b->candUb};
     for (DevBuf *d : bufs) d->release();
     b->stage.release();
     b->stageIn.release();
@@ -2503,6 +2891,21 @@ static bool pretest_applies(const sfm_ctx *ctx, const double *K, int loss)
     return K[2] == 0.0 && K[5] == 0.0 && K[8] == 1.0 && K[1] == 0.0 && K[3] == 0.0 && fx > 0.0 && fy > 0.0 &&
            std::isfinite(fx) && std::isfinite(fy) && std::isfinite(1.0 / fx) && std::isfinite(1.0 / fy) &&
            ctx->ransac_filter != 0 && loss != SFM_LOSS_SAMPSON;
+}
+
+// The matrix-core scoring kernel for 16 x tiles rows per wave; pre: the correspondence side was prepared; defer:
+// rows with many inliers are handed over to ransac_heavy_eval_kernel.
+template <int LOSS>
+static void (*mfma_score_kernel(int tiles, bool pre, bool defer))(const RansacArgs)
+{
+    if (pre && defer)
+        return tiles == 1 ? ransac_score_mfma_kernel<1, true, LOSS, true>
+             : tiles == 2 ? ransac_score_mfma_kernel<2, true, LOSS, true> : ransac_score_mfma_kernel<4, true, LOSS, true>;
+    if (pre)
+        return tiles == 1 ? ransac_score_mfma_kernel<1, true, LOSS>
+             : tiles == 2 ? ransac_score_mfma_kernel<2, true, LOSS> : ransac_score_mfma_kernel<4, true, LOSS>;
+    return tiles == 1 ? ransac_score_mfma_kernel<1, false, LOSS>
+         : tiles == 2 ? ransac_score_mfma_kernel<2, false, LOSS> : ransac_score_mfma_kernel<4, false, LOSS>;
 }
 
 static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
@@ -2691,25 +3094,67 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     g.active = b->active.as<int>();
     g.maxIter = b->maxIter.as<int>();
     SFM_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)b->active.p, 1, (size_t)n_pairs, st));
+    int64_t maxN = 0;
+    for (int p = 0; p < n_pairs; p++) maxN = std::max(maxN, corr_offsets[p + 1] - corr_offsets[p]);
+    // Will the scoring launches run the test on the matrix cores from prepared operands?  Then rows with many
+    // inliers can be handed over to the cell-by-cell kernels (a buffer of one error per cell of such a row, as many
+    // rows as the budget holds), and a row that cannot reach the best count of the slices before is passed over:
+    // reason enough to score in slices also when no iteration cap is in force.
+    const size_t opsBytes = (mfma_ops_start(total, n_pairs) + 1) * 2048;
+    const bool opsFit = !no_alloc && ctx->ransac_mfma_ops_gib > 0 && opsBytes <= ((size_t)ctx->ransac_mfma_ops_gib << 30);
+    const bool mfmaPath = !fit_only && g.mfma && ((g.filter && loss == SFM_LOSS_REPROJECTION) || sampsonTest) && opsFit &&
+                          split_factor(ctx, n_pairs, std::min(n_hyp, 256), total) == 1;
+    g.heavyMax = 0;
+    g.heavyStride = (int)((maxN + 255) / 256 * 256);
+    if (mfmaPath && ctx->ransac_defer_gib > 0 && maxN >= 16 * 4 * DEFER_CHECK_STEPS && n_hyp > 0) {
+        const size_t perRow = (size_t)g.heavyStride * sizeof(double);
+        int64_t slots = (int64_t)(((size_t)ctx->ransac_defer_gib << 30) / perRow);
+        slots = std::min<int64_t>(slots, ((int64_t)n_pairs * n_hyp + 63) / 64 * 64) / 64 * 64;
+        slots = std::min<int64_t>(slots, 1 << 20);
+        if (slots >= 64 && b->heavyErr.reserve((size_t)slots * perRow) == hipSuccess) {
+            const int64_t cands = std::min<int64_t>((int64_t)n_pairs * n_hyp, 1 << 22);
+            SFM_HIP(ctx, b->heavyRow.reserve((size_t)slots * sizeof(long long)));
+            SFM_HIP(ctx, b->heavyCount.reserve(2 * sizeof(unsigned int)));
+            SFM_HIP(ctx, b->candRow.reserve((size_t)cands * sizeof(long long)));
+            SFM_HIP(ctx, b->candUb.reserve((size_t)cands * sizeof(unsigned int)));
+            g.heavyMax = (int)slots;
+            g.candMax = (int)cands;
+            g.heavyErr = b->heavyErr.as<double>();
+            g.heavyRow = b->heavyRow.as<long long>();
+            g.heavyCount = b->heavyCount.as<unsigned int>();
+            g.candRow = b->candRow.as<long long>();
+            g.candUb = b->candUb.as<unsigned int>();
+        } else if (slots >= 64) {
+            (void)hipGetLastError(); // no room: the waves keep their rows
+        }
+    }
+    const bool defer = g.heavyMax > 0;
     int bounds[40]; // slices grow by a factor of four: at most 17 of them below 2^31 rows
     int nBounds = 0;
     bounds[nBounds++] = 0;
-    if (phased && adaptive && !fit_only) {
+    if (phased && !fit_only && (adaptive || defer)) {
         // The first slice is as small as its launch can be made efficient: 256 rows (one block of rows
         // per pair; with most correspondences inliers the cap falls below that at once) when the scoring
         // launch can be split over correspondences with a moderate buffer, otherwise enough rows to fill
         // the device twice over (a CU holds four blocks of the scoring kernel: 8 blocks per CU are two full
         // rounds, and with slices growing by four the later launches are whole rounds too when the pair count
-        // divides evenly).
-        const int64_t fill = 8 * (int64_t)ctx->n_cus;
+        // divides evenly).  Where rows can be handed over, a quarter of that (half without a cap) and a growth
+        // of eight: the first slice has no count to beat yet, so each of its rows with many inliers is
+        // evaluated in full, and every slice after it ends with the device running empty once (measured on 256
+        // pairs of 20000 correspondences: at 80 % inliers the smaller slice is worth a third of the time, at
+        // 15 % the larger one a twentieth).
+        const int64_t fill = (defer ? (adaptive ? 2 : 4) : 8) * (int64_t)ctx->n_cus;
         int64_t h = 256 * std::max<int64_t>(1, (fill + n_pairs - 1) / n_pairs);
         if (!no_alloc && split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
         if (ctx->hyps_per_launch > 0) h = 64 * ((ctx->hyps_per_launch + 63) / 64); // caller's first slice
         // (a single pair whose scan has stopped still pays a few microseconds for every later slice's
         // launches: its slices grow by eight, a batch's by four)
+        int grow = (n_pairs == 1 || defer) ? 8 : 4;
+        if (const char *e = getenv("SFM_DEBUG_GROWTH")) grow = atoi(e);
+        if (!adaptive) grow = 1 << 20; // (no cap to wait for: the first slice finds a count to beat, the second takes the rest)
         while (h < n_hyp && nBounds < 38) {
             bounds[nBounds++] = (int)h;
-            h *= (n_pairs == 1) ? 8 : 4;
+            h *= grow;
         }
     }
     bounds[nBounds++] = n_hyp;
@@ -2730,6 +3175,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             if (!no_alloc) SFM_HIP(ctx, sfm_span_begin(ctx, 1));
             const dim3 grid((rows + 255) / 256, n_pairs, Z);
             const bool pretest = g.filter != 0;
+            bool handOver = false;
             double *eb = nullptr;
             if (Z > 1) {
                 SFM_HIP(ctx, b->errBuf.reserve(errBytes));
@@ -2748,24 +3194,43 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                 // The correspondence side of the test is made once per call (128 B per correspondence) when the
                 // table fits the budget; otherwise, and for the entry point that allocates nothing, every block
                 // makes it from the fp32 records as it goes.
-                const size_t opsBytes = (mfma_ops_start(total, n_pairs) + 1) * 2048;
-                if (!opsTried && !no_alloc && ctx->ransac_mfma_ops_gib > 0 && opsBytes <= ((size_t)ctx->ransac_mfma_ops_gib << 30)) {
+                if (!opsTried && opsFit) {
                     opsTried = true;
                     if (b->mfOps.reserve(opsBytes) == hipSuccess) {
                         g.mfOps = b->mfOps.as<uint4>();
-                        int64_t maxN = 0;
-                        for (int p = 0; p < n_pairs; p++) maxN = std::max(maxN, corr_offsets[p + 1] - corr_offsets[p]);
                         const unsigned gxOps = (unsigned)((((maxN + 15) / 16) * 32 + 255) / 256);
                         if (gxOps > 0) hipLaunchKernelGGL(ransac_mfma_ops_kernel, dim3(gxOps, n_pairs), dim3(256), 0, st, g);
                     } else {
                         (void)hipGetLastError(); // no room: the blocks make their operands
                     }
                 }
-                const dim3 mgrid((unsigned)(((rows + 255) / 256) * n_pairs));
-                void (*mk)(const RansacArgs) = g.mfOps ? ransac_score_mfma_kernel<4, true> : ransac_score_mfma_kernel<4, false>;
-                if (sampsonTest)
-                    mk = g.mfOps ? ransac_score_mfma_kernel<4, true, SFM_LOSS_SAMPSON> : ransac_score_mfma_kernel<4, false, SFM_LOSS_SAMPSON>;
+                int tiles = 4;
+                if (const char *e = getenv("SFM_DEBUG_T")) tiles = atoi(e);
+                if (ph == 0) if (const char *e = getenv("SFM_DEBUG_T0")) tiles = atoi(e);
+                const bool pre = g.mfOps != nullptr;
+                handOver = pre && defer && tiles == 4;
+                if (const char *e = getenv("SFM_DEBUG_DEFER")) handOver = handOver && atoi(e) != 0;
+                const int rowsB = 64 * tiles;
+                const dim3 mgrid((unsigned)(((rows + rowsB - 1) / rowsB) * n_pairs));
+                if (handOver) {
+                    // (the bound needs the packed test: the reprojection error under plain intrinsics)
+                    g.heavyBound = (ph > 0 && g.filter && loss == SFM_LOSS_REPROJECTION) ? 1 : 0;
+                    SFM_HIP(ctx, hipMemsetAsync(g.heavyCount, 0, 2 * sizeof(unsigned int), st));
+                    hipLaunchKernelGGL(ransac_heavy_find_kernel, dim3((unsigned)(((rows + 255) / 256) * n_pairs)), dim3(256), 0, st, g);
+                    if (g.heavyBound) hipLaunchKernelGGL(ransac_heavy_bound_kernel, dim3((unsigned)(8 * ctx->n_cus)), dim3(256), 0, st, g);
+                    hipLaunchKernelGGL(ransac_heavy_assign_kernel, dim3((unsigned)ctx->n_cus), dim3(256), 0, st, g);
+                }
+                void (*mk)(const RansacArgs) = sampsonTest ? mfma_score_kernel<SFM_LOSS_SAMPSON>(tiles, pre, handOver)
+                                                           : mfma_score_kernel<SFM_LOSS_REPROJECTION>(tiles, pre, handOver);
                 hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
+                if (handOver) {
+                    const unsigned evalBlocks = (unsigned)(8 * ctx->n_cus);
+                    if (sampsonTest)
+                        hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_SAMPSON>, dim3(evalBlocks), dim3(256), 0, st, g);
+                    else
+                        hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_REPROJECTION>, dim3(evalBlocks), dim3(256), 0, st, g);
+                    hipLaunchKernelGGL(ransac_heavy_sum_kernel, dim3((unsigned)(g.heavyMax / 64)), dim3(256), 0, st, g);
+                }
             }
             else
                 hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
@@ -2780,8 +3245,6 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         hipLaunchKernelGGL(ransac_select_kernel, dim3(n_pairs), dim3(256), 0, st, g);
     }
     if (!fit_only) {
-        int64_t maxN = 0;
-        for (int p = 0; p < n_pairs; p++) maxN = std::max(maxN, corr_offsets[p + 1] - corr_offsets[p]);
         const int nBlk = (int)std::max<int64_t>(1, (maxN + 255) / 256);
         SFM_HIP(ctx, b->inlFlag.reserve((size_t)(total ? total : 1)));
         SFM_HIP(ctx, b->inlBlk.reserve((size_t)n_pairs * nBlk * sizeof(int)));
