@@ -763,6 +763,7 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank, comm=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         best = batch.best()
+        best["rows_with_many_inliers"] = dict(zip(("candidates", "passed_over", "handed_over"), batch.handed_over()))
         if g is not None:
             if rank == 0:  # what arrived: every pair of the whole list, and this rank's own share unchanged
                 r = g.ransac()
@@ -824,8 +825,10 @@ def bench_ransac(ctx, args, rank, world, dist, local_rank, comm=None):
                 el2, kms2, _, best2 = measure(256, 64, ratio, True, filt, 1, 50 + int(ratio * 10))
                 rows.append({"inlier_ratio": ratio, "pre_test": bool(filt), "pairs": 256,
                              "all_rows_scored": {"hyps_per_s": round(256 * H / el, 1), "score_kernel_ms": round(kms, 3),
+                                                 "rows_with_many_inliers": best["rows_with_many_inliers"],
                                                  "mean_best_inliers": float(np.mean(best["count"]))},
                              "adaptive_stop": {"pairs_per_s": round(256 / el2, 1), "score_kernel_ms": round(kms2, 3),
+                                               "rows_with_many_inliers": best2["rows_with_many_inliers"],
                                                "mean_iterations": float(np.mean(best2["iterations"])),
                                                "mean_best_inliers": float(np.mean(best2["count"]))}})
                 if not filt and kms > 0:  # every cell evaluated exactly: the kernel's own roofline

@@ -363,6 +363,15 @@ int sfm_ransac_batch_inliers(sfm_ransac_batch *b, int32_t *inliers_out);
 int sfm_ransac_batch_refit(sfm_ransac_batch *b);
 int sfm_ransac_batch_refit_fetch(sfm_ransac_batch *b, double *pose16_out, int32_t *used_out,
                                  double *points_out);
+/* How the last run dealt with sample rows that hold many inliers (no counterpart in the
+ * reference, whose loop evaluates every correspondence of every row in turn,
+ * RANSAC.cpp:207-221): rows found to pass the pre-test on more than a set share of a
+ * pair's first correspondences (candidates), of which those that could not reach the
+ * best count of the slices before and were left at count 0 (passed over), and those
+ * evaluated cell by cell by kernels of their own (handed over); the rest stayed with
+ * the scoring kernel.  Results do not depend on any of this.  Any output may be NULL. */
+int sfm_ransac_batch_handed_over(sfm_ransac_batch *b, int64_t *candidates_out, int64_t *passed_over_out,
+                                 int64_t *handed_over_out);
 void sfm_ransac_batch_destroy(sfm_ransac_batch *b);
 
 /* ---- binary descriptors (extension) -----------------------------------------

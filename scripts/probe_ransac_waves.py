@@ -1,3 +1,9 @@
+"""Waves of the matrix-core scoring kernel: cells evaluated, drains, running times (measurement build only).
+Build the library with the counters into a file of its own and point SFM_AMD_LIB at it:
+  cd sfm_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+     -DSFM_DEBUG_WAVES -c ransac.hip -o /tmp/ransac_dbg.o && hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libsfm_amd_dbg.so \
+     context.o match.o /tmp/ransac_dbg.o pipeline.o chain.o hamming.o comm.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  SFM_AMD_LIB=/tmp/libsfm_amd_dbg.so python scripts/probe_ransac_waves.py [ratio] [adaptive] [first slice]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "sfm_match_result_destroy",
     "sfm_ransac_pair", "sfm_ransac_pair_static", "sfm_eight_point_fit", "sfm_eight_point_from_subset", "sfm_eight_point_algorithm", "sfm_ransac_batch_run", "sfm_ransac_batch_run_device",
     "sfm_ransac_batch_best", "sfm_ransac_batch_inlier_offsets", "sfm_ransac_batch_inliers",
-    "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch",
+    "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch", "sfm_ransac_batch_handed_over",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
     "sfm_match_batch_ratio", "sfm_match_batch_l2", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
     L.sfm_ransac_batch_destroy.restype = None
     L.sfm_ransac_batch_refit.argtypes = [vp]
     L.sfm_ransac_batch_refit_fetch.argtypes = [vp, vp, vp, vp]
+    L.sfm_ransac_batch_handed_over.argtypes = [vp, vp, vp, vp]
     L.sfm_corr_from_matches.argtypes = [vp, vp, vp, vp, P(vp)]
     L.sfm_corr_offsets.argtypes = [vp, vp]
     L.sfm_corr_device.argtypes = [vp, P(vp), P(vp)]
@@ -795,6 +796,12 @@ class RansacBatch:
         off = np.zeros(self.n_pairs + 1, np.int64)
         self.ctx.check(lib().sfm_ransac_batch_inlier_offsets(self._h, _ptr(off)))
         return off
+
+    def handed_over(self):
+        """(candidates, passed over, handed over): sample rows with many inliers, as the last run dealt with them."""
+        c, p, h = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.ctx.check(lib().sfm_ransac_batch_handed_over(self._h, C.byref(c), C.byref(p), C.byref(h)))
+        return int(c.value), int(p.value), int(h.value)
 
     def inliers(self):
         off = self.inlier_offsets()

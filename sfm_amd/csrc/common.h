@@ -31,7 +31,7 @@ struct sfm_ctx {
     int64_t hyps_per_launch = 0;     // rows of the first slice of an adaptive RANSAC batch (0 = sized to fill the device)
     int ransac_filter = 1;           // 0 disables the scoring kernel's epipolar pre-test
     int ransac_mfma = 1;             // 0: the pre-test of unsplit launches stays on the vector ALU (packed fp32)
-    int ransac_defer_gib = 2;        // buffer for the rows a scoring launch hands over to cell-by-cell evaluation (8 B per cell of such a row), GiB; 0: none
+    int ransac_defer_mib = 2048;     // buffer for the rows a scoring launch hands over to cell-by-cell evaluation (8 B per cell of such a row), MiB; 0: rows are never handed over
     int ransac_mfma_ops_gib = 64;    // largest table of prepared matrix-core operands (128 B per correspondence) a call may hold, GiB; 0: none
     int ransac_split = 1;            // 0: never cut a pair's correspondences across blocks
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only

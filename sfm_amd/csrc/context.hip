@@ -136,9 +136,9 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->ransac_filter = value != 0;
     } else if (!strcmp(key, "ransac_mfma")) {
         ctx->ransac_mfma = value != 0;
-    } else if (!strcmp(key, "ransac_defer_gib")) {
-        if (value < 0 || value > 4096) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac_defer_gib must be in [0, 4096]");
-        ctx->ransac_defer_gib = (int)value;
+    } else if (!strcmp(key, "ransac_defer_mib")) {
+        if (value < 0 || value > (1 << 20)) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac_defer_mib must be in [0, 1048576]");
+        ctx->ransac_defer_mib = (int)value;
     } else if (!strcmp(key, "ransac_mfma_ops_gib")) {
         if (value < 0 || value > 4096) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "ransac_mfma_ops_gib must be in [0, 4096]");
         ctx->ransac_mfma_ops_gib = (int)value;

@@ -61,7 +61,8 @@ struct RansacArgs {
     int mfKe;     // and scale the hypothesis side of num by 2^mfKe
     double mfI[2]; // that test's 1/fx, 1/fy: the camera's for the reprojection loss, 2/(fx + fy) twice for the Sampson distance
     // rows with many inliers, handed over for evaluation cell by cell (see ransac_heavy_find_kernel)
-    unsigned int *heavyCount; // [0]: candidates found in this slice, [1]: slots claimed (both may run past their limits: claims beyond were refused)
+    unsigned int *heavyCount; // [0]: candidates found in this slice, [1]: slots claimed (both may run past their limits: claims beyond were refused);
+                              // of the whole call: [2] candidates settled, [3] passed over, [4] handed over
     long long *candRow;       // [candMax] pair << 32 | row
     unsigned int *candUb;     // [candMax] cells of the row that pass the packed test: an upper bound of its count
     long long *heavyRow;      // [heavyMax] pair << 32 | row of the slot
@@ -1739,42 +1740,75 @@ __global__ __launch_bounds__(256) void ransac_heavy_find_kernel(const RansacArgs
 
 // The cells of a candidate row that pass the packed fp32 test of ransac_score_kernel (a cell that fails it lies
 // too far from its epipolar line to be an inlier): their number bounds the row's count from above.  A block
-// per candidate, in turn.
+// takes BOUND_GROUP consecutive candidates in turn; those of one pair (the waves that find them list the rows of
+// a pair together) share the reads of the pair's records, which are what the kernel waits for.
+#define BOUND_GROUP 4
 __global__ __launch_bounds__(256) void ransac_heavy_bound_kernel(const RansacArgs g)
 {
-    __shared__ unsigned int part[4];
+    __shared__ unsigned int part[4][BOUND_GROUP];
     const int cands = (int)min(g.heavyCount[0], (unsigned)g.candMax);
     const double skipDist = SKIP_FACTOR * sqrt(g.maxSqErr);
-    for (int c = blockIdx.x; c < cands; c += gridDim.x) {
-        const long long hr = g.candRow[c];
-        const int p = (int)(hr >> 32), row = (int)(hr & 0xFFFFFFFFll);
-        const int64_t base = g.corrOff[p];
-        const int n = (int)(g.corrOff[p + 1] - base);
-        Pose Q;
-        load_pose(g.pose12 + ((size_t)p * g.H + row) * 12, Q);
-        double E[3][3];
-        essential_from_pose(Q, E);
-        float Ef[9];
+    for (int c0 = blockIdx.x * BOUND_GROUP; c0 < cands; c0 += gridDim.x * BOUND_GROUP) {
+        int pj[BOUND_GROUP];
+        float Ef[BOUND_GROUP][9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) Ef[i] = (float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] * skipDist : (i < 6 ? g.Ki[1] * skipDist : 1.0)));
-        const float *rec = g.rec32 + rec32_start(base, p);
-        unsigned int cnt = 0;
-        for (int k = threadIdx.x; k < n; k += 256) {
-            const float *grp = rec + (size_t)(k >> 2) * 20 + (k & 3);
-            const float x1 = grp[0], y1 = grp[4], u2 = grp[8], v2 = grp[12], gg = grp[16];
-            const float m0 = __builtin_fmaf(Ef[0], x1, __builtin_fmaf(Ef[1], y1, Ef[2]));
-            const float m1 = __builtin_fmaf(Ef[3], x1, __builtin_fmaf(Ef[4], y1, Ef[5]));
-            const float m2 = __builtin_fmaf(Ef[6], x1, __builtin_fmaf(Ef[7], y1, Ef[8]));
-            const float num = __builtin_fmaf(u2, m0, __builtin_fmaf(v2, m1, m2));
-            const float q = __builtin_fmaf(m0, m0, __builtin_fmaf(m1, m1, gg));
-            cnt += !(num * num >= q) ? 1u : 0u; // (a NaN passes)
+        for (int j = 0; j < BOUND_GROUP; j++) {
+            pj[j] = -1;
+            if (c0 + j < cands) {
+                const long long hr = g.candRow[c0 + j];
+                pj[j] = (int)(hr >> 32);
+                Pose Q;
+                load_pose(g.pose12 + ((size_t)pj[j] * g.H + (int)(hr & 0xFFFFFFFFll)) * 12, Q);
+                double E[3][3];
+                essential_from_pose(Q, E);
+#pragma unroll
+                for (int i = 0; i < 9; i++)
+                    Ef[j][i] = (float)(E[i / 3][i % 3] * (i < 3 ? g.Ki[0] * skipDist : (i < 6 ? g.Ki[1] * skipDist : 1.0)));
+            }
         }
+        unsigned todo = 0;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) g.candUb[c] = (part[0] + part[1]) + (part[2] + part[3]);
-        __syncthreads();
+        for (int j = 0; j < BOUND_GROUP; j++) todo |= (pj[j] >= 0 ? 1u : 0u) << j;
+        while (todo) { // the candidates of the first open one's pair together
+            int p = -1;
+            unsigned grp = 0;
+#pragma unroll
+            for (int j = 0; j < BOUND_GROUP; j++) {
+                if (((todo >> j) & 1u) && p < 0) p = pj[j];
+                if (((todo >> j) & 1u) && pj[j] == p) grp |= 1u << j;
+            }
+            todo &= ~grp;
+            const int64_t base = g.corrOff[p];
+            const int n = (int)(g.corrOff[p + 1] - base);
+            const float *rec = g.rec32 + rec32_start(base, p);
+            unsigned int cnt[BOUND_GROUP];
+#pragma unroll
+            for (int j = 0; j < BOUND_GROUP; j++) cnt[j] = 0;
+            for (int k = threadIdx.x; k < n; k += 256) {
+                const float *grpRec = rec + (size_t)(k >> 2) * 20 + (k & 3);
+                const float x1 = grpRec[0], y1 = grpRec[4], u2 = grpRec[8], v2 = grpRec[12], gg = grpRec[16];
+#pragma unroll
+                for (int j = 0; j < BOUND_GROUP; j++) {
+                    if (!((grp >> j) & 1u)) continue;
+                    const float m0 = __builtin_fmaf(Ef[j][0], x1, __builtin_fmaf(Ef[j][1], y1, Ef[j][2]));
+                    const float m1 = __builtin_fmaf(Ef[j][3], x1, __builtin_fmaf(Ef[j][4], y1, Ef[j][5]));
+                    const float m2 = __builtin_fmaf(Ef[j][6], x1, __builtin_fmaf(Ef[j][7], y1, Ef[j][8]));
+                    const float num = __builtin_fmaf(u2, m0, __builtin_fmaf(v2, m1, m2));
+                    const float q = __builtin_fmaf(m0, m0, __builtin_fmaf(m1, m1, gg));
+                    cnt[j] += !(num * num >= q) ? 1u : 0u; // (a NaN passes)
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BOUND_GROUP; j++) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) cnt[j] += __shfl_xor(cnt[j], d);
+                if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][j] = cnt[j];
+            }
+            __syncthreads();
+            if (threadIdx.x < BOUND_GROUP && ((grp >> threadIdx.x) & 1u))
+                g.candUb[c0 + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+            __syncthreads();
+        }
     }
 }
 
@@ -1800,6 +1834,14 @@ __global__ __launch_bounds__(256) void ransac_heavy_assign_kernel(const RansacAr
             }
         }
         if (mark) g.counts[(size_t)p * g.H + row] = mark;
+        // (tallies of the call, for sfm_ransac_batch_handed_over: a wave adds up its lanes)
+        const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+        const unsigned long long pa = __builtin_amdgcn_ballot_w64(mark == ROW_PASSED), ha = __builtin_amdgcn_ballot_w64(mark == ROW_HANDED);
+        if ((threadIdx.x & 63) == __builtin_ctzll(all)) {
+            atomicAdd(&g.heavyCount[2], (unsigned)__builtin_popcountll(all));
+            if (pa) atomicAdd(&g.heavyCount[3], (unsigned)__builtin_popcountll(pa));
+            if (ha) atomicAdd(&g.heavyCount[4], (unsigned)__builtin_popcountll(ha));
+        }
     }
 }
 
@@ -2851,6 +2893,9 @@ struct sfm_ransac_batch {
     bool refitted = false; // sfm_ransac_batch_refit ran on the last run's result
     std::vector<int64_t> corrOffHost; // the last run's offsets
     ReadFence readFence; // a gather on another stream still reads the winners' records and inlier lists up to this point
+    // the rows handed over are evaluated on a stream of their own, beside the scoring kernel that left them out
+    hipStream_t side = nullptr;
+    hipEvent_t sideGo = nullptr, sideDone = nullptr;
 };
 
 extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
@@ -2866,6 +2911,9 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     b->stage.release();
     b->stageIn.release();
     b->readFence.destroy();
+    if (b->side) (void)hipStreamDestroy(b->side);
+    if (b->sideGo) (void)hipEventDestroy(b->sideGo);
+    if (b->sideDone) (void)hipEventDestroy(b->sideDone);
     sfm_ctx *owner = b->ctx;
     delete b;
     sfm_ctx_release(owner);
@@ -2893,19 +2941,14 @@ static bool pretest_applies(const sfm_ctx *ctx, const double *K, int loss)
            ctx->ransac_filter != 0 && loss != SFM_LOSS_SAMPSON;
 }
 
-// The matrix-core scoring kernel for 16 x tiles rows per wave; pre: the correspondence side was prepared; defer:
-// rows with many inliers are handed over to ransac_heavy_eval_kernel.
+// The matrix-core scoring kernel (64 rows per wave); pre: the correspondence side was prepared; defer: rows with
+// many inliers were handed over to ransac_heavy_eval_kernel.
 template <int LOSS>
-static void (*mfma_score_kernel(int tiles, bool pre, bool defer))(const RansacArgs)
+static void (*mfma_score_kernel(bool pre, bool defer))(const RansacArgs)
 {
-    if (pre && defer)
-        return tiles == 1 ? ransac_score_mfma_kernel<1, true, LOSS, true>
-             : tiles == 2 ? ransac_score_mfma_kernel<2, true, LOSS, true> : ransac_score_mfma_kernel<4, true, LOSS, true>;
-    if (pre)
-        return tiles == 1 ? ransac_score_mfma_kernel<1, true, LOSS>
-             : tiles == 2 ? ransac_score_mfma_kernel<2, true, LOSS> : ransac_score_mfma_kernel<4, true, LOSS>;
-    return tiles == 1 ? ransac_score_mfma_kernel<1, false, LOSS>
-         : tiles == 2 ? ransac_score_mfma_kernel<2, false, LOSS> : ransac_score_mfma_kernel<4, false, LOSS>;
+    if (pre && defer) return ransac_score_mfma_kernel<4, true, LOSS, true>;
+    if (pre) return ransac_score_mfma_kernel<4, true, LOSS>;
+    return ransac_score_mfma_kernel<4, false, LOSS>;
 }
 
 static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, const double *x, const double *y,
@@ -3106,17 +3149,23 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                           split_factor(ctx, n_pairs, std::min(n_hyp, 256), total) == 1;
     g.heavyMax = 0;
     g.heavyStride = (int)((maxN + 255) / 256 * 256);
-    if (mfmaPath && ctx->ransac_defer_gib > 0 && maxN >= 16 * 4 * DEFER_CHECK_STEPS && n_hyp > 0) {
+    if (mfmaPath && ctx->ransac_defer_mib > 0 && maxN >= 16 * 4 * DEFER_CHECK_STEPS && n_hyp > 0) {
         const size_t perRow = (size_t)g.heavyStride * sizeof(double);
-        int64_t slots = (int64_t)(((size_t)ctx->ransac_defer_gib << 30) / perRow);
+        int64_t slots = (int64_t)(((size_t)ctx->ransac_defer_mib << 20) / perRow);
         slots = std::min<int64_t>(slots, ((int64_t)n_pairs * n_hyp + 63) / 64 * 64) / 64 * 64;
         slots = std::min<int64_t>(slots, 1 << 20);
         if (slots >= 64 && b->heavyErr.reserve((size_t)slots * perRow) == hipSuccess) {
             const int64_t cands = std::min<int64_t>((int64_t)n_pairs * n_hyp, 1 << 22);
             SFM_HIP(ctx, b->heavyRow.reserve((size_t)slots * sizeof(long long)));
-            SFM_HIP(ctx, b->heavyCount.reserve(2 * sizeof(unsigned int)));
+            SFM_HIP(ctx, b->heavyCount.reserve(8 * sizeof(unsigned int)));
+            SFM_HIP(ctx, hipMemsetAsync(b->heavyCount.p, 0, 8 * sizeof(unsigned int), st));
             SFM_HIP(ctx, b->candRow.reserve((size_t)cands * sizeof(long long)));
             SFM_HIP(ctx, b->candUb.reserve((size_t)cands * sizeof(unsigned int)));
+            if (!b->side) {
+                SFM_HIP(ctx, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+                SFM_HIP(ctx, hipEventCreateWithFlags(&b->sideGo, hipEventDisableTiming));
+                SFM_HIP(ctx, hipEventCreateWithFlags(&b->sideDone, hipEventDisableTiming));
+            }
             g.heavyMax = (int)slots;
             g.candMax = (int)cands;
             g.heavyErr = b->heavyErr.as<double>();
@@ -3150,7 +3199,6 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         // (a single pair whose scan has stopped still pays a few microseconds for every later slice's
         // launches: its slices grow by eight, a batch's by four)
         int grow = (n_pairs == 1 || defer) ? 8 : 4;
-        if (const char *e = getenv("SFM_DEBUG_GROWTH")) grow = atoi(e);
         if (!adaptive) grow = 1 << 20; // (no cap to wait for: the first slice finds a count to beat, the second takes the rest)
         while (h < n_hyp && nBounds < 38) {
             bounds[nBounds++] = (int)h;
@@ -3204,14 +3252,9 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                         (void)hipGetLastError(); // no room: the blocks make their operands
                     }
                 }
-                int tiles = 4;
-                if (const char *e = getenv("SFM_DEBUG_T")) tiles = atoi(e);
-                if (ph == 0) if (const char *e = getenv("SFM_DEBUG_T0")) tiles = atoi(e);
                 const bool pre = g.mfOps != nullptr;
-                handOver = pre && defer && tiles == 4;
-                if (const char *e = getenv("SFM_DEBUG_DEFER")) handOver = handOver && atoi(e) != 0;
-                const int rowsB = 64 * tiles;
-                const dim3 mgrid((unsigned)(((rows + rowsB - 1) / rowsB) * n_pairs));
+                handOver = pre && defer;
+                const dim3 mgrid((unsigned)(((rows + 255) / 256) * n_pairs));
                 if (handOver) {
                     // (the bound needs the packed test: the reprojection error under plain intrinsics)
                     g.heavyBound = (ph > 0 && g.filter && loss == SFM_LOSS_REPROJECTION) ? 1 : 0;
@@ -3220,17 +3263,21 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                     if (g.heavyBound) hipLaunchKernelGGL(ransac_heavy_bound_kernel, dim3((unsigned)(8 * ctx->n_cus)), dim3(256), 0, st, g);
                     hipLaunchKernelGGL(ransac_heavy_assign_kernel, dim3((unsigned)ctx->n_cus), dim3(256), 0, st, g);
                 }
-                void (*mk)(const RansacArgs) = sampsonTest ? mfma_score_kernel<SFM_LOSS_SAMPSON>(tiles, pre, handOver)
-                                                           : mfma_score_kernel<SFM_LOSS_REPROJECTION>(tiles, pre, handOver);
-                hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
-                if (handOver) {
+                void (*mk)(const RansacArgs) = sampsonTest ? mfma_score_kernel<SFM_LOSS_SAMPSON>(pre, handOver)
+                                                           : mfma_score_kernel<SFM_LOSS_REPROJECTION>(pre, handOver);
+                if (handOver) { // the rows handed over, beside the scoring kernel
+                    SFM_HIP(ctx, hipEventRecord(b->sideGo, st));
+                    SFM_HIP(ctx, hipStreamWaitEvent(b->side, b->sideGo, 0));
                     const unsigned evalBlocks = (unsigned)(8 * ctx->n_cus);
                     if (sampsonTest)
-                        hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_SAMPSON>, dim3(evalBlocks), dim3(256), 0, st, g);
+                        hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_SAMPSON>, dim3(evalBlocks), dim3(256), 0, b->side, g);
                     else
-                        hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_REPROJECTION>, dim3(evalBlocks), dim3(256), 0, st, g);
-                    hipLaunchKernelGGL(ransac_heavy_sum_kernel, dim3((unsigned)(g.heavyMax / 64)), dim3(256), 0, st, g);
+                        hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_REPROJECTION>, dim3(evalBlocks), dim3(256), 0, b->side, g);
+                    hipLaunchKernelGGL(ransac_heavy_sum_kernel, dim3((unsigned)(g.heavyMax / 64)), dim3(256), 0, b->side, g);
+                    SFM_HIP(ctx, hipEventRecord(b->sideDone, b->side));
                 }
+                hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
+                if (handOver) SFM_HIP(ctx, hipStreamWaitEvent(st, b->sideDone, 0));
             }
             else
                 hipLaunchKernelGGL(score, grid, dim3(256), 0, st, g, eb);
@@ -3281,6 +3328,24 @@ extern "C" int sfm_ransac_batch_refit(sfm_ransac_batch *b)
     hipLaunchKernelGGL(ransac_refit_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->args, rf);
     SFM_HIP(ctx, hipGetLastError());
     b->refitted = true;
+    return SFM_OK;
+}
+
+extern "C" int sfm_ransac_batch_handed_over(sfm_ransac_batch *b, int64_t *candidates_out, int64_t *passed_over_out,
+                                            int64_t *handed_over_out)
+{
+    if (!b) return SFM_ERR_INVALID_ARG;
+    sfm_ctx *ctx = b->ctx;
+    if (!b->scored) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "handed_over: the batch holds no RANSAC result");
+    unsigned int t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (b->args.heavyMax > 0) {
+        SFM_HIP(ctx, hipSetDevice(ctx->device));
+        SFM_HIP(ctx, hipMemcpyAsync(t, b->args.heavyCount, sizeof t, hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (candidates_out) *candidates_out = t[2];
+    if (passed_over_out) *passed_over_out = t[3];
+    if (handed_over_out) *handed_over_out = t[4];
     return SFM_OK;
 }
 

@@ -600,3 +600,99 @@ def test_stress_batch_against_restatement(ctx, oracle):
         pose12 = np.concatenate([e["pose"][:3, :3].reshape(-1), e["pose"][:3, 3]])
         assert np.array_equal(best["pose12"][k].view(np.uint64), pose12.view(np.uint64))
     b.close()
+
+
+def _heavy_batch(sizes, H, seed, ratios=(0.8, 0.6, 0.9)):
+    xs, ys, Ss, off = [], [], [], [0]
+    for k, n in enumerate(sizes):
+        tv = synth.two_view(n, inlier_ratio=ratios[k % len(ratios)], seed=[seed, k], noise_px=0.4)
+        xs.append(tv["x"]); ys.append(tv["y"])
+        Ss.append(synth.sample_table(n, H, seed=[seed + 1, k]))
+        off.append(off[-1] + n)
+    return xs, ys, Ss, np.array(off, np.int64)
+
+
+def _assert_winners(best, ioff, inl, xs, ys, Ss, K, oracle, adaptive, loss=capi.LOSS_REPROJECTION, thr=1.0):
+    for k in range(len(xs)):
+        kw = dict(loss_kind=loss) if loss != capi.LOSS_REPROJECTION else {}
+        e = oracle.ransac(xs[k], ys[k], K, Ss[k], max_sq_err=thr, success_prob=0.999, adaptive=adaptive, **kw)
+        assert best["best_h"][k] == e["best_h"], k
+        assert best["iterations"][k] == e["iterations"], k
+        assert best["count"][k] == len(e["inliers"]), k
+        assert best["toterr"][k] == e["toterr"][e["best_h"]], k
+        assert np.array_equal(inl[ioff[k]:ioff[k + 1]], e["inliers"]), k
+
+
+@pytest.mark.parametrize("adaptive", [True, False])
+@pytest.mark.parametrize("defer_mib", [2048, 3, 0])
+def test_rows_handed_over_are_the_restatement_s(ctx, oracle, adaptive, defer_mib):
+    """Pairs with most correspondences inliers: many sample rows hold thousands of inliers, and the scoring launch
+    hands them over to the cell-by-cell kernels (with 3 MiB the buffer holds 64 such rows at a time, so most of
+    them stay with the scoring kernel; with 0 none is handed over).  Pairs of unequal sizes, one too short to be
+    searched for such rows; slices of 128 rows so that later slices have a count to beat and rows are passed
+    over.  Winner, count, error sum, iterations and inlier list are the CPU restatement's (RANSAC.cpp:207-258)."""
+    sizes = [5000, 4500, 3000, 5555, 4100, 4700, 5000, 4321, 6000]  # (more than one group of eight)
+    H = 640
+    xs, ys, Ss, off = _heavy_batch(sizes, H, 700)
+    K = synth.default_K()
+    ctx.set_option("ransac_split", 0)
+    ctx.set_option("ransac_defer_mib", defer_mib)
+    ctx.set_option("hyps_per_launch", 128)
+    try:
+        b = ctx.ransac_batch(off, np.concatenate(xs), np.concatenate(ys), K, np.concatenate(Ss), H, max_sq_err=1.0,
+                             success_prob=0.999, adaptive=adaptive)
+        best = b.best()
+        ioff, inl = b.inliers()
+        cands, passed, handed = b.handed_over()
+        b.close()
+    finally:
+        ctx.set_option("ransac_split", 1)
+        ctx.set_option("ransac_defer_mib", 2048)
+        ctx.set_option("hyps_per_launch", 0)
+    print("candidates", cands, "passed over", passed, "handed over", handed)
+    if defer_mib == 0:
+        assert cands == 0
+    else:
+        assert handed >= 64 and passed > 0 and passed + handed <= cands
+        assert (passed + handed < cands) == (defer_mib == 3)  # the small buffer leaves rows with the scoring kernel
+    assert (best["count"] * 8 > np.array(sizes)).sum() >= 6  # rows with more than an eighth of the cells inliers did occur
+    _assert_winners(best, ioff, inl, xs, ys, Ss, K, oracle, adaptive)
+
+
+def test_rows_handed_over_with_the_sampson_distance(ctx, oracle):
+    """The same with the Sampson distance as the loss: no packed test, so no row is passed over, but rows are
+    handed over all the same."""
+    sizes = [4200, 5000, 4600]
+    H = 384
+    xs, ys, Ss, off = _heavy_batch(sizes, H, 720)
+    K = synth.default_K()
+    ctx.set_option("ransac_split", 0)
+    try:
+        b = ctx.ransac_batch(off, np.concatenate(xs), np.concatenate(ys), K, np.concatenate(Ss), H, max_sq_err=1.0,
+                             success_prob=0.999, adaptive=True, loss=capi.LOSS_SAMPSON)
+        best = b.best()
+        ioff, inl = b.inliers()
+        cands, passed, handed = b.handed_over()
+        b.close()
+    finally:
+        ctx.set_option("ransac_split", 1)
+    assert handed > 0 and passed == 0
+    _assert_winners(best, ioff, inl, xs, ys, Ss, K, oracle, True, loss=capi.LOSS_SAMPSON)
+
+
+def test_rows_handed_over_keep_every_row_s_score(ctx, oracle):
+    """A single pair scored with per-row outputs (one slice, nothing to beat): rows handed over get their exact
+    count and error sum from the cell-by-cell kernels, every other row from the scoring kernel."""
+    n, H = 6000, 512
+    tv = synth.two_view(n, inlier_ratio=0.85, seed=[730, 0], noise_px=0.3)
+    S = synth.sample_table(n, H, seed=[731, 0])
+    ctx.set_option("ransac_split", 0)
+    try:
+        got = ctx.ransac_pair(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    finally:
+        ctx.set_option("ransac_split", 1)
+    exp = oracle.ransac(tv["x"], tv["y"], tv["K"], S, max_sq_err=1.0, success_prob=0.999, adaptive=True)
+    assert (exp["counts"] > n // 8).sum() > 5
+    assert np.array_equal(got["counts"], exp["counts"])
+    assert np.array_equal(got["toterr"].view(np.uint64), exp["toterr"].view(np.uint64))
+    assert_same_run(got, exp)
