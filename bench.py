@@ -292,7 +292,7 @@ def main():
             "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1), args.bound),
             "traffic_unit": "HBM bytes per launch",
             "traffic_source": "static, not measured in this run: bytes per pair from the committed rocprofv3 PMC passes "
-                              "(profiles/r2_pmc_traffic_i8.json, r1_pmc_traffic.json for the fp16 bound: separate FETCH_SIZE / WRITE_SIZE "
+                              "(profiles/r3_pmc_traffic_i8.json, r1_pmc_traffic.json for the fp16 bound: separate FETCH_SIZE / WRITE_SIZE "
                               "runs of this script, scripts/pmc_traffic.sh) "
                               "times this run's pairs per launch",
             "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4), "launches": kernel_launches,
@@ -374,7 +374,7 @@ def measured_traffic(pairs_per_launch, bound="int8"):
     """HBM bytes per launch of the similarity kernel from the committed PMC pass (FETCH_SIZE and
     WRITE_SIZE are collected by rocprofv3 in separate runs of this script, not inline), scaled to
     this run's pairs per launch; None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic_i8.json" if bound == "int8" else "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic_i8.json" if bound == "int8" else "r1_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -672,19 +672,20 @@ def ransac_valu_profile(mfma):
     shape, from the committed counter pass of the kernel that runs (static; None if the file is absent).
     Returns (instructions, correspondences per group, extra fields, source)."""
     if mfma:
-        path = os.path.join(ROOT, "profiles", "r2e_pmc_sq_ransac_mfma.json")
-        if os.path.exists(path):
-            with open(path) as f:
+        name = next((f for f in ("r3_pmc_sq_ransac_mfma.json", "r2e_pmc_sq_ransac_mfma.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        if name:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
             for k, v in t.items():
                 if isinstance(v, dict) and "ransac_score_mfma_kernel" in k:
-                    extra = {"kernel": "ransac_score_mfma_kernel",
+                    extra = {"kernel": k.replace("void ", "").replace("(RansacArgs)", ""), "tree_of_the_counter_pass": v.get("tree", "round 2"),
                              "vector_instructions_per_wave_per_16_correspondences": v["vector_instructions_per_wave_step"],
                              "of_which_mfma": v["mfma_instructions_per_wave_step"],
                              "matrix_pipe_busy_fraction_of_simd_cycles_under_counters": round(v["mfma_busy_fraction_of_simd_cycles"], 4),
                              "valu_busy_fraction_of_simd_cycles_under_counters": round(v["valu_busy_fraction_of_simd_cycles"], 4),
                              "clock_GHz_under_counters": round(v["clock_GHz_under_load"], 3)}
-                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/r2e_pmc_sq_ransac_mfma.json"
+                    return v["vector_instructions_per_wave_step"], 16, extra, "profiles/" + name
         return None, None, None, None
     for name in ("r2_pmc_sq_ransac.json", "r1_final4_pmc_sq_ransac.json"):
         path = os.path.join(ROOT, "profiles", name)
