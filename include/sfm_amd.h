@@ -81,6 +81,10 @@ const char *sfm_version(void);
  * operands, 128 bytes per correspondence, that a RANSAC call may allocate, in
  * GiB, default 64; 0 or a call that needs more = every block makes the
  * operands of its correspondences as it goes; results are identical),
+ * "ransac_defer_mib" (buffer, in MiB, default 2048, for the sample rows with
+ * many inliers that a batch scored from prepared operands evaluates cell by cell
+ * with kernels of their own, 8 bytes per correspondence of such a row; 0 = every
+ * row stays in the scoring kernel; results are identical),
  * "chain_table_entries" (entries of the
  * scale chain's (step, track) table, default 2^26; a sequence that needs more
  * goes through in windows of steps; results are identical), "hamming_mfma"

@@ -71,7 +71,9 @@ def test_random_batch(ctx, oracle, seed):
     loss = int(rng.choice([0, 0, 1]))
     xs, ys, Ss, off = [], [], [], [0]
     for k in range(P):
-        n = int(rng.choice([0, 5, 8, 15, 16, 17, 63, 64, 65, 500, 1023, 2500, 6000], p=[.03, .03, .05, .05, .05, .05, .05, .05, .05, .2, .15, .14, .1]))
+        # (4096 correspondences and more: sample rows with many inliers may be handed over to the cell-by-cell kernels)
+        n = int(rng.choice([0, 5, 8, 15, 16, 17, 63, 64, 65, 500, 1023, 2500, 4095, 4096, 4500, 6000, 9001],
+                           p=[.03, .03, .05, .05, .05, .05, .05, .05, .05, .15, .1, .09, .05, .05, .05, .05, .05]))
         tv = synth.two_view(max(n, 8), inlier_ratio=float(rng.choice([0.15, 0.5, 0.9])), seed=int(rng.integers(1 << 30)),
                             noise_px=float(rng.choice([0.0, 0.5, 2.0])), K=K)
         x, y = tv["x"][:n].copy(), tv["y"][:n].copy()
@@ -85,6 +87,8 @@ def test_random_batch(ctx, oracle, seed):
     ctx.set_option("ransac_split", int(rng.integers(2)))
     ctx.set_option("ransac_mfma", int(rng.integers(2)))
     ctx.set_option("ransac_mfma_ops_gib", int(rng.choice([0, 64])))
+    ctx.set_option("ransac_defer_mib", int(rng.choice([0, 5, 2048, 2048])))  # (5 MiB: 64 rows of 9001 correspondences at a time)
+    ctx.set_option("hyps_per_launch", int(rng.choice([0, 0, 64, 192])))      # rows of the first slice
     try:
         b = ctx.ransac_batch(np.array(off), x, y, K, S, H, max_sq_err=thr, success_prob=0.999, adaptive=adaptive, loss=loss)
         best = b.best()
@@ -94,6 +98,8 @@ def test_random_batch(ctx, oracle, seed):
         ctx.set_option("ransac_split", 1)
         ctx.set_option("ransac_mfma", 1)
         ctx.set_option("ransac_mfma_ops_gib", 64)
+        ctx.set_option("ransac_defer_mib", 2048)
+        ctx.set_option("hyps_per_launch", 0)
     for k in range(P):
         n = off[k + 1] - off[k]
         if n < 8:
