@@ -679,7 +679,7 @@ def ransac_valu_profile(mfma):
                 t = json.load(f)
             for k, v in t.items():
                 if isinstance(v, dict) and "ransac_score_mfma_kernel" in k:
-                    extra = {"kernel": k.replace("void ", "").replace("(RansacArgs)", ""), "tree_of_the_counter_pass": v.get("tree", "round 2"),
+                    extra = {"kernel": k.replace("void ", "").replace("(RansacArgs)", ""), "tree_of_the_counter_pass": v.get("tree", "an earlier tree"),
                              "vector_instructions_per_wave_per_16_correspondences": v["vector_instructions_per_wave_step"],
                              "of_which_mfma": v["mfma_instructions_per_wave_step"],
                              "matrix_pipe_busy_fraction_of_simd_cycles_under_counters": round(v["mfma_busy_fraction_of_simd_cycles"], 4),
