@@ -112,6 +112,8 @@ def main():
     ctx.set_option("sim_variant", sim_variant)
     if "SFM_MATCH_OVERLAP" in os.environ:  # A/B switch of the matcher's two-stream chunk overlap
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
+    if "SFM_MATCH_LIST_OBSERVE" in os.environ:  # A/B switch: match lists sized as the call goes / for the worst case
+        ctx.set_option("match_list_observe", int(os.environ["SFM_MATCH_LIST_OBSERVE"]))
     if "SFM_RANSAC_MFMA" in os.environ:  # A/B switch: the RANSAC pre-test on the matrix cores (1) or the vector ALU (0)
         ctx.set_option("ransac_mfma", int(os.environ["SFM_RANSAC_MFMA"]))
     if "SFM_RANSAC_MFMA_OPS_GIB" in os.environ:  # A/B switch: 0 = every block makes the matrix-core operands of its correspondences

@@ -91,6 +91,11 @@ const char *sfm_version(void);
  * (1 = 256-bit binary descriptors are first matched on the matrix cores as
  * sign vectors, default; 0 = popcount kernel only; results are identical),
  * "ransac_seed" / "ransac_max_time_ms" (single-pair RANSAC: see sfm_ransac_pair),
+ * "match_list_observe" (1, default: a batch call of more than 32 chunks does not
+ * allocate its match lists for the worst case, min(nA, nB) entries per pair, but
+ * keeps the buffer ahead of the running total that the device reports chunk by
+ * chunk, growing it at most a few times; 2 = calls of more than 8 chunks do; 0 =
+ * always the worst case; results are identical),
  * "match_overlap" (1 = a batch of several chunks runs what follows a chunk's
  * bound passes on a second stream of the context while the next chunk's bound
  * passes start, default; 0 = everything on one stream; results are identical;

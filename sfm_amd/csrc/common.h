@@ -37,6 +37,7 @@ struct sfm_ctx {
     int hamming_mfma = 1;            // 0: 256-bit binary descriptors take the popcount kernel only
     int match_col_split = 0;         // column parts per row block in the matcher's strict passes; 0 = chosen per call from the launch size
     int match_overlap = 1;           // 0: the matcher's chunks run one after the other on `stream` only
+    int match_list_observe = 1;      // 0: a batch call allocates its match lists for the worst case (min(nA, nB) per pair) up front; 1: calls of more than 32 chunks size them as they go; 2: calls of more than 8 chunks do
     // Two more streams of the batch matcher and the events that order the three.  stream2: what follows a
     // chunk's first bound pass; stream3: the uploads of the next chunk's records and their bounds.  ev[0..2]
     // a chunk's first bound pass is done, ev[3..5] its buffer set is clear again, ev[7..9] its records are on

@@ -124,6 +124,9 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->match_pair_reuse = value != 0;
     } else if (!strcmp(key, "cand_observe")) {
         ctx->cand_observe = value != 0;
+    } else if (!strcmp(key, "match_list_observe")) {
+        if (value < 0 || value > 2) SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "match_list_observe must be 0, 1 or 2");
+        ctx->match_list_observe = (int)value;
     } else if (!strcmp(key, "match_overlap")) {
         ctx->match_overlap = value != 0;
     } else if (!strcmp(key, "match_col_split")) {

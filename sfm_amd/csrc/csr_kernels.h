@@ -113,5 +113,4 @@ __global__ __launch_bounds__(1024) void match_scan_kernel(const int *__restrict_
     }
 }
 
-
 } // namespace

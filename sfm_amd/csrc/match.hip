@@ -1721,6 +1721,10 @@ extern "C" void sfm_match_result_destroy(sfm_match_result *r)
     if (r->upDone) (void)hipEventDestroy(r->upDone);
     if (r->statsEv) (void)hipEventDestroy(r->statsEv);
     r->hostStats.release();
+    r->hostTotals.release();
+    for (hipEvent_t &e : r->listEv)
+        if (e) (void)hipEventDestroy(e);
+    for (void *q : r->retired) (void)hipFree(q);
     DevBuf *bufs[] = {&r->offsets, &r->pairs, &r->pairRecs, &r->work, &r->cand, &r->candCount, &r->pairOvf,
                       &r->best, &r->ovfList, &r->counts, &r->stats, &r->m1, &r->kill, &r->candProbe, &r->rowMax};
     for (DevBuf *b : bufs) b->release();
@@ -1772,6 +1776,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         }
     }
     res->upValid = false;
+    for (void *q : res->retired) (void)hipFree(q); // list buffers the call before outgrew (hipFree waits for the device)
+    res->retired.clear();
     // a gather of the call before may still read this result's lists on the communicator's stream
     SFM_HIP(ctx, res->readFence.wait_on(ctx->stream));
     res->n_pairs = n_pairs;
@@ -1837,6 +1843,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         return ((orient ? nB : nA) + BLOCK_ROWS - 1) / BLOCK_ROWS;
     };
     int64_t mostBlocks = 0; // row blocks of image A in the chunk that has most
+    std::vector<int64_t> chunkWorst((size_t)nChunks, 0); // most matches a chunk can have: min(nA, nB) per pair
     for (int cj = 0; cj < nChunks; cj++) {
         const int c0 = cstart[cj], c1 = cstart[cj + 1];
         int64_t bestOff = 0, blocks = 0;
@@ -1847,6 +1854,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             const int nA = set->images[ia].n, nB = set->images[ib].n;
             bestOff += (int64_t)nA + nB;
             outTotalCap += std::min(nA, nB);
+            chunkWorst[cj] += std::min(nA, nB);
             maxNA = std::max(maxNA, nA);
             maxNB = std::max(maxNB, nB);
             blocks += row_blocks(nA, nB, 0);
@@ -1938,7 +1946,34 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->pairRecs.reserve((size_t)(n_pairs ? n_pairs : 1) * sizeof(PairRec)));
     SFM_HIP(ctx, res->work.reserve((size_t)(workTotal ? workTotal : 1) * sizeof(int2)));
     SFM_HIP(ctx, res->offsets.reserve((size_t)(n_pairs + 1) * sizeof(int64_t)));
-    SFM_HIP(ctx, res->pairs.reserve((size_t)(outTotalCap ? outTotalCap : 1) * sizeof(int2)));
+    // Match lists.  The worst case, min(nA, nB) matches per pair, is 64 KiB per pair of 8192 x 8192 (33 GB for half a
+    // million pairs) and several times what selective thresholds leave.  A call of more than 4 LIST_RING chunks
+    // therefore starts with room for the worst case of its first LIST_RING chunks (or what the result object
+    // already holds), lets the device report the running total after every chunk (a copy into page-locked memory,
+    // an event per chunk), and keeps the buffer at least as large as the last total it has seen plus the worst case
+    // of every chunk enqueued since.  The host runs at most LIST_RING chunks ahead of the lists (the device stays
+    // busy: a chunk takes ~10 ms, its enqueue well under 1), so the seen total is recent; when the buffer must grow
+    // it grows once to 1.15 times the total extrapolated from the pairs seen, the lists so far move over on the
+    // stream that writes them, and the old buffer is freed when the next call starts.  Shorter calls keep the
+    // worst case: it is small there, and the host running far ahead is worth 1-2 % of the time (measured on the
+    // benchmark's 10 chunks: 201 k against 197 k pairs/s).
+    constexpr int LIST_RING = 8;
+    const bool listObserve = ctx->match_list_observe != 0 && (nChunks > 4 * LIST_RING || ctx->match_list_observe > 1) &&
+                             nChunks > LIST_RING && !want_m1m2;
+    int64_t listCap = outTotalCap ? outTotalCap : 1; // entries
+    if (listObserve) {
+        int64_t first = 0;
+        for (int cj = 0; cj < LIST_RING; cj++) first += chunkWorst[cj];
+        listCap = std::min(listCap, std::max<int64_t>(first, 1));
+        SFM_HIP(ctx, res->hostTotals.reserve((size_t)nChunks * sizeof(int64_t)));
+        for (int cj = 0; cj < nChunks; cj++) res->hostTotals.as<int64_t>()[cj] = -1;
+        for (hipEvent_t &e : res->listEv)
+            if (!e) SFM_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    SFM_HIP(ctx, res->pairs.reserve((size_t)listCap * sizeof(int2)));
+    listCap = (int64_t)(res->pairs.cap / sizeof(int2)); // (what the buffer holds: a reused result may hold more)
+    int listKnown = -1;          // last chunk whose running total the host has seen
+    int64_t listKnownTotal = 0;  // that total
     // Chunks in flight: while chunk c + 1 runs its bound passes on the context's stream, the exact pass, the
     // mutual check and the list output of chunk c run on a second stream, in the gaps the bound pass leaves
     // (its blocks fill the register files: kernels with few registers run beside it, the exact pass mostly
@@ -2228,6 +2263,42 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[par], 0));
             }
         }
+        if (listObserve) {
+            int64_t *const totals = res->hostTotals.as<int64_t>();
+            auto learn = [&]() -> hipError_t { // the total after the next chunk not yet seen (waits for that chunk's lists)
+                const hipError_t e = hipEventSynchronize(res->listEv[(listKnown + 1) % LIST_RING]);
+                if (e != hipSuccess) return e;
+                listKnown++;
+                listKnownTotal = totals[listKnown];
+                if (listKnownTotal < 0) // (not what a completed event allows; the offsets themselves are complete by now)
+                    return hipMemcpy(&listKnownTotal, res->offsets.as<int64_t>() + cstart[listKnown + 1], sizeof(int64_t), hipMemcpyDeviceToHost);
+                return hipSuccess;
+            };
+            auto need = [&]() {
+                int64_t s = listKnownTotal;
+                for (int cj = listKnown + 1; cj <= (int)ci; cj++) s += chunkWorst[cj];
+                return s;
+            };
+            while (listKnown < (int)ci - LIST_RING) SFM_HIP(ctx, learn()); // (this chunk takes the event of chunk ci - LIST_RING)
+            while (need() > listCap && listKnown < (int)ci - 1) SFM_HIP(ctx, learn());
+            if (need() > listCap) {
+                int64_t est = outTotalCap;
+                if (listKnown >= 0 && cstart[listKnown + 1] > 0) {
+                    est = (int64_t)((double)listKnownTotal / cstart[listKnown + 1] * n_pairs * 1.15);
+                    for (int cj = (int)ci; cj < std::min<int>(nChunks, (int)ci + LIST_RING); cj++) est += chunkWorst[cj];
+                }
+                const int64_t newCap = std::min<int64_t>(outTotalCap, std::max(need(), est));
+                void *grown = nullptr;
+                SFM_HIP(ctx, hipMalloc(&grown, (size_t)newCap * sizeof(int2) + 256));
+                const int64_t written = need() - chunkWorst[ci]; // no list so far reaches beyond this
+                if (written > 0)
+                    SFM_HIP(ctx, hipMemcpyAsync(grown, res->pairs.p, (size_t)written * sizeof(int2), hipMemcpyDeviceToDevice, st));
+                res->retired.push_back(res->pairs.p);
+                res->pairs.p = grown;
+                res->pairs.cap = (size_t)newCap * sizeof(int2) + 256;
+                listCap = newCap;
+            }
+        }
         // (the scan continues the offsets of the chunk before: same stream, in order)
         if (np == 1) { // one pair: its list starts at the offset before it, no counting pass and no scan
             hipLaunchKernelGGL((match_mutual_kernel<true, 16>), dim3(1), dim3(1024), 0, st, g.pairs, g.best, (int *)nullptr,
@@ -2243,6 +2314,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             hipLaunchKernelGGL((match_mutual_kernel<true>), dim3(np), dim3(256), 0, st, g.pairs, g.best,
                                (int *)nullptr, res->offsets.as<int64_t>() + c0, res->pairs.as<int2>(),
                                (int32_t *)nullptr, (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
+        }
+        if (listObserve) {
+            SFM_HIP(ctx, hipMemcpyAsync(res->hostTotals.as<int64_t>() + ci, res->offsets.as<int64_t>() + c1, sizeof(int64_t),
+                                        hipMemcpyDeviceToHost, st));
+            SFM_HIP(ctx, hipEventRecord(res->listEv[ci % LIST_RING], st));
         }
         if (overlap && ci + sets < (size_t)nChunks) { // clear the set for the chunk that takes it next (sizes: upper bounds)
             if (maxBest > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)maxBest * sizeof(u64), st));

@@ -111,6 +111,12 @@ struct sfm_match_result {
     PinBuf hostStats;
     hipEvent_t done = nullptr; // recorded on the context's stream when a batch call has enqueued all its work
     ReadFence readFence;       // a gather on another stream still reads offsets / pairs up to this point
+    // match lists sized as a call goes (option match_list_observe): the running total after every chunk, written
+    // by the device into page-locked memory, an event per chunk in flight, and list buffers that a call outgrew
+    // (freed when the next call starts or the result goes)
+    PinBuf hostTotals;
+    hipEvent_t listEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<void *> retired;
 };
 int sfm_match_result_mark_done(sfm_ctx *ctx, sfm_match_result *res);
 

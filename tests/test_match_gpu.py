@@ -709,3 +709,39 @@ def test_reused_frame_is_the_copy_on_the_device(ctx, oracle):
     assert len(exp_before) > 10 and not np.array_equal(exp_before, exp_now)
     assert np.array_equal(kept, exp_before)
     assert np.array_equal(now, exp_now)
+
+
+@pytest.mark.parametrize("threshold", [0.95, 0.5])
+def test_lists_sized_as_the_call_goes_are_the_same_lists(ctx, threshold):
+    """A batch of many chunks starts with room for the worst case of its first eight chunks and keeps its list
+    buffer ahead of the running total the device reports (growing it once, the lists so far moving over), instead
+    of allocating min(nA, nB) entries per pair up front.  Same offsets and lists as with the worst case allocated,
+    in less memory; a second call on the result object finds the room it needs and allocates nothing."""
+    n_img, n = 28, 400
+    d, p, c = synth.image_set(n_img, n, seed=31)
+    pl = synth.exhaustive_pairs(n_img)  # 378 pairs, 48 chunks of 8
+    s = ctx.imageset(c, d, p)
+    ctx.set_option("pairs_per_launch", 8)
+    try:
+        ctx.set_option("match_list_observe", 0)
+        ref = s.match(pl, threshold=threshold)
+        off0, pairs0, bytes0 = ref.offsets(), ref.pairs(), ref.device_bytes()
+        ref.close()
+        ctx.set_option("match_list_observe", 2)  # (1, the default, waits for calls of more than 32 chunks: see below)
+        res = s.match(pl, threshold=threshold)
+        off1, pairs1, bytes1 = res.offsets(), res.pairs(), res.device_bytes()
+        res = s.match(pl, threshold=threshold, result=res)
+        off2, pairs2, bytes2 = res.offsets(), res.pairs(), res.device_bytes()
+        res.close()
+    finally:
+        ctx.set_option("pairs_per_launch", 2048)
+        ctx.set_option("match_list_observe", 1)
+    s.close()
+    assert int(off0[-1]) > 8 * 8 * n  # more matches than the first eight chunks could hold at worst: the buffer grew
+    assert np.array_equal(off0, off1) and np.array_equal(pairs0, pairs1)
+    assert np.array_equal(off0, off2) and np.array_equal(pairs0, pairs2)
+    worst = len(pl) * n * 8
+    print("list bytes: worst case", worst, "result objects", bytes0, bytes1, bytes2, "matches", int(off0[-1]))
+    assert bytes2 == bytes1 and bytes1 < bytes0  # (at threshold 0.5 most keypoints find a partner: little to save)
+    if threshold > 0.9:
+        assert bytes0 - bytes1 > worst // 3
