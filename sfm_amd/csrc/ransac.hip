@@ -1299,7 +1299,7 @@ extern "C" int sfm_debug_wave_stats(unsigned long long *out)
 // ROW_PASSED rows cannot matter to the scan and stay at count 0.  Neither gets operands here, so none of their
 // cells passes the test; the sums of ROW_HANDED rows are not written.
 #define DEFER_CHECK_STEPS 64 // steps of 16 correspondences over which ransac_heavy_find_kernel counts
-#define DEFER_SHARE_FIRST 8  // a row is a candidate when more than one in this many of those cells pass the test: first slice,
+#define DEFER_SHARE_FIRST 8    // a row is a candidate when more than one in this many of those cells pass the test: first slice,
 #define DEFER_SHARE_LATER 32 // and later slices when a bound can be had (most candidates are then passed over)
 #define ROW_HANDED (-1)
 #define ROW_PASSED (-2)
@@ -3131,7 +3131,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
     // Phases of hypothesis rows.  With the adaptive cap on, a pair whose in-order scan has stopped
     // needs no further rows, so rows are fitted and scored in growing slices and the scan is resumed
     // after each; the first slice is sized to fill the device (a slice's grid is rows / 256 blocks
-    // per pair).  Without the cap, or when the caller wants every row's score, one phase covers all.
+    // per pair).  When the caller wants every row's score one phase covers all; without the cap, two (see below)
+    // where rows with many inliers can be handed over, else one.
     SFM_HIP(ctx, b->active.reserve(P1 * sizeof(int)));
     SFM_HIP(ctx, b->maxIter.reserve(P1 * sizeof(int)));
     g.active = b->active.as<int>();
