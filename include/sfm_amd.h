@@ -459,6 +459,25 @@ int sfm_scale_chain(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int
                     const double *points, const double *poses16, const double *start_pose16,
                     double max_translation, int n_tracks, double *extrinsics_out,
                     double *points3d_out, int32_t *counts_out, double *acc_scale_out);
+/* The same with the colour of every track (scene.cpp:377, :394-407): colors[total][3]
+ * is the colour of the observation behind every point (what
+ * util::getPixelBilinearUchar returns for it, scene.cpp:377; sfm_pixel_bilinear_u8
+ * below computes it); the first sighting of a track stores it, every later one
+ * that updates the running mean updates the colour too, per channel in float
+ * arithmetic, clamped to [0, 255] and cut off towards zero (:394-407).
+ * colors_out[n_tracks][3] (zeros for tracks never seen). */
+int sfm_scale_chain_colors(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int32_t *track_ids,
+                           const double *points, const uint8_t *colors, const double *poses16,
+                           const double *start_pose16, double max_translation, int n_tracks,
+                           double *extrinsics_out, double *points3d_out, uint8_t *colors_out,
+                           int32_t *counts_out, double *acc_scale_out);
+/* util::getPixelBilinearUchar (submodules/util/util.cpp:40-78) for n positions of
+ * one image: bgr[rows][cols][3] bytes as OpenCV holds them, pixels[n][2] = (u, v)
+ * (column, row; denormalizePoints of a correspondence, scene.cpp:377), rgb_out[n][3].
+ * The four neighbours' weights and the weighted sum in double, rounded to the
+ * nearest integer (ties to even) and clamped, as cv::saturate_cast<uchar> does. */
+int sfm_pixel_bilinear_u8(sfm_ctx *ctx, const uint8_t *bgr, int rows, int cols, const double *pixels, int n,
+                          uint8_t *rgb_out);
 /* Same, reading poses and points of the steps from a refitted RANSAC batch
  * without leaving the device (pair p of the batch = step p; its point set is
  * the refit's: the inlier list when that has at least 8 entries, else all

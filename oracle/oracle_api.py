@@ -321,6 +321,50 @@ def scale_chain(offsets, track_ids, points, poses, start_pose=None, max_translat
                 counts=cnt[:n_tracks], scale=scale[:S])
 
 
+def scale_chain_colors(offsets, track_ids, points, colors, poses, start_pose=None, max_translation=15.0, n_tracks=0):
+    """scale_chain with the running colour average of scene.cpp:394-407; colors uint8 [total, 3]."""
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    S = len(offsets) - 1
+    pad = lambda a, shape, dt: a if a.size else np.zeros(shape, dt)
+    track_ids = pad(np.ascontiguousarray(track_ids, np.int32), 1, np.int32)
+    points = pad(np.ascontiguousarray(points, np.float64).reshape(-1, 3), (1, 3), np.float64)
+    colors = pad(np.ascontiguousarray(colors, np.uint8).reshape(-1, 3), (1, 3), np.uint8)
+    poses_c = pad(np.ascontiguousarray(np.asarray(poses, np.float64).reshape(S, 4, 4).transpose(0, 2, 1)), (1, 4, 4),
+                  np.float64)
+    start = np.eye(4) if start_pose is None else np.asarray(start_pose, np.float64)
+    start_c = np.ascontiguousarray(start.T)
+    extr = np.zeros((S + 1, 16))
+    pts = np.zeros((max(n_tracks, 1), 3))
+    cols = np.zeros((max(n_tracks, 1), 3), np.uint8)
+    cnt = np.zeros(max(n_tracks, 1), np.int32)
+    scale = np.zeros(max(S, 1))
+    f = lib().sfm_oracle_scale_chain_colors
+    f.restype = C.c_int
+    vp = C.c_void_p
+    f.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp, vp, vp, vp]
+    P = lambda a: a.ctypes.data_as(vp)
+    rc = f(S, P(offsets), P(track_ids), P(points), P(colors), P(poses_c), P(start_c), float(max_translation), int(n_tracks),
+           P(extr), P(pts), P(cols), P(cnt), P(scale))
+    if rc != 0:
+        raise MemoryError("scale chain")
+    return dict(extrinsics=extr.reshape(S + 1, 4, 4).transpose(0, 2, 1).copy(), points3d=pts[:n_tracks],
+                colors=cols[:n_tracks], counts=cnt[:n_tracks], scale=scale[:S])
+
+
+def pixel_bilinear_u8(image_bgr, pixels):
+    """util::getPixelBilinearUchar (util.cpp:40-78) at every (u, v) of pixels: RGB uint8 [n, 3]."""
+    img = np.ascontiguousarray(image_bgr, np.uint8)
+    rows, cols = img.shape[:2]
+    px = np.ascontiguousarray(pixels, np.float64).reshape(-1, 2)
+    out = np.zeros((max(len(px), 1), 3), np.uint8)
+    f = lib().sfm_oracle_pixel_bilinear_u8
+    f.restype = None
+    vp = C.c_void_p
+    f.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    f(img.ctypes.data_as(vp), rows, cols, px.ctypes.data_as(vp), len(px), out.ctypes.data_as(vp))
+    return out[:len(px)]
+
+
 def match_hamming(descA, ptsA, descB, ptsB, max_distance=64, max_dist_sq=1e8):
     """Mutual nearest neighbours of binary descriptors (uint8 [n, bytes]) under the Hamming distance.
     Returns (pairs[k,2] int32, matches1[nA], matches2[nB])."""

@@ -1467,9 +1467,12 @@ static void pose_apply(const double *P, const double *p, double *out)
         out[r] = ((P[r] * p[0] + P[r + 4] * p[1]) + P[r + 8] * p[2]) + P[r + 12];
 }
 
-int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *track_ids, const double *points,
-                           const double *poses16, const double *start_pose16, double max_translation, int n_tracks,
-                           double *extrinsics_out, double *points3d_out, int32_t *counts_out, double *acc_scale_out)
+/* colors (optional): the colour of the observation behind every point (scene.cpp:377), three bytes per row;
+ * colors_out[n_tracks][3] then receives the running average of scene.cpp:394-407. */
+static int scale_chain_impl(int n_steps, const int64_t *offsets, const int32_t *track_ids, const double *points,
+                            const unsigned char *colors, const double *poses16, const double *start_pose16,
+                            double max_translation, int n_tracks, double *extrinsics_out, double *points3d_out,
+                            unsigned char *colors_out, int32_t *counts_out, double *acc_scale_out)
 {
     double accScale = 1.0, accPose[16];
     memcpy(accPose, start_pose16, sizeof accPose);
@@ -1477,6 +1480,7 @@ int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *t
     for (int t = 0; t < n_tracks; t++) {
         points3d_out[3 * t] = points3d_out[3 * t + 1] = points3d_out[3 * t + 2] = 0.0;
         counts_out[t] = 0;
+        if (colors_out) colors_out[3 * t] = colors_out[3 * t + 1] = colors_out[3 * t + 2] = 0;
     }
     double *ratios = (double *)malloc(sizeof(double) * (size_t)(offsets[n_steps] > 0 ? offsets[n_steps] : 1));
     if (!ratios) return -1;
@@ -1522,14 +1526,25 @@ int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *t
             double g[3];
             pose_apply(accPose, sp, g);
             double *cur = points3d_out + 3 * t;
+            const unsigned char *nc = (colors && colors_out) ? colors + 3 * (b23 + j) : NULL;
             if (counts_out[t] == 0) {
                 cur[0] = g[0]; cur[1] = g[1]; cur[2] = g[2];
+                if (nc) for (int c = 0; c < 3; c++) colors_out[3 * t + c] = nc[c];
                 counts_out[t] = 1;
             } else {
                 const double d0 = cur[0] - g[0], d1 = cur[1] - g[1], d2 = cur[2] - g[2];
                 if (sqrt((d0 * d0 + d1 * d1) + d2 * d2) < 50.0) {
-                    const double N1 = (double)(counts_out[t] + 1);
+                    const int N = counts_out[t];
+                    const double N1 = (double)(N + 1);
                     for (int r = 0; r < 3; r++) cur[r] = cur[r] + (g[r] - cur[r]) / N1;
+                    if (nc) { /* accumulateUchar, scene.cpp:394-402: float arithmetic, clamp, cut off */
+                        for (int c = 0; c < 3; c++) {
+                            const float cNew = (float)nc[c], cOld = (float)colors_out[3 * t + c];
+                            float res = cOld + (cNew - cOld) / (float)(N + 1);
+                            res = res < 0.f ? 0.f : (res > 255.f ? 255.f : res);
+                            colors_out[3 * t + c] = (unsigned char)res;
+                        }
+                    }
                     counts_out[t]++;
                 }
             }
@@ -1541,6 +1556,50 @@ int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *t
     }
     free(ratios);
     return 0;
+}
+
+int sfm_oracle_scale_chain(int n_steps, const int64_t *offsets, const int32_t *track_ids, const double *points,
+                           const double *poses16, const double *start_pose16, double max_translation, int n_tracks,
+                           double *extrinsics_out, double *points3d_out, int32_t *counts_out, double *acc_scale_out)
+{
+    return scale_chain_impl(n_steps, offsets, track_ids, points, NULL, poses16, start_pose16, max_translation, n_tracks,
+                            extrinsics_out, points3d_out, NULL, counts_out, acc_scale_out);
+}
+
+int sfm_oracle_scale_chain_colors(int n_steps, const int64_t *offsets, const int32_t *track_ids, const double *points,
+                                  const unsigned char *colors, const double *poses16, const double *start_pose16,
+                                  double max_translation, int n_tracks, double *extrinsics_out, double *points3d_out,
+                                  unsigned char *colors_out, int32_t *counts_out, double *acc_scale_out)
+{
+    return scale_chain_impl(n_steps, offsets, track_ids, points, colors, poses16, start_pose16, max_translation, n_tracks,
+                            extrinsics_out, points3d_out, colors_out, counts_out, acc_scale_out);
+}
+
+/* util::getPixelBilinearUchar (submodules/util/util.cpp:40-78) for n positions (u, v) of one image of BGR bytes:
+ * RGB bytes out.  cv::saturate_cast<uchar>(double) is cvRound (nearest, ties to even) and a clamp. */
+void sfm_oracle_pixel_bilinear_u8(const unsigned char *bgr, int rows, int cols, const double *pixels, int n,
+                                  unsigned char *rgb_out)
+{
+    for (int i = 0; i < n; i++) {
+        const double u = pixels[2 * i], v = pixels[2 * i + 1];
+        int x0 = (int)floor(u), y0 = (int)floor(v);
+        x0 = x0 < 0 ? 0 : (x0 > cols - 2 ? cols - 2 : x0);
+        y0 = y0 < 0 ? 0 : (y0 > rows - 2 ? rows - 2 : y0);
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const double dx = u - x0, dy = v - y0;
+        const double w00 = (1.0 - dx) * (1.0 - dy), w10 = dx * (1.0 - dy), w01 = (1.0 - dx) * dy, w11 = dx * dy;
+        const unsigned char *p00 = bgr + 3 * ((size_t)y0 * cols + x0), *p10 = bgr + 3 * ((size_t)y0 * cols + x1);
+        const unsigned char *p01 = bgr + 3 * ((size_t)y1 * cols + x0), *p11 = bgr + 3 * ((size_t)y1 * cols + x1);
+        unsigned char res[3];
+        for (int c = 0; c < 3; c++) {
+            const double val = ((w00 * p00[c] + w10 * p10[c]) + w01 * p01[c]) + w11 * p11[c];
+            const double r = nearbyint(val);
+            res[c] = (unsigned char)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+        }
+        rgb_out[3 * i] = res[2]; /* BGR -> RGB */
+        rgb_out[3 * i + 1] = res[1];
+        rgb_out[3 * i + 2] = res[0];
+    }
 }
 
 /* ---------------------------------------------------------------------------------------------

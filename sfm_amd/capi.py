@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "sfm_ransac_batch_destroy", "sfm_ransac_batch_refit", "sfm_ransac_batch_refit_fetch", "sfm_ransac_batch_handed_over",
     "sfm_corr_from_matches", "sfm_corr_offsets", "sfm_corr_device", "sfm_corr_fetch", "sfm_corr_sample_table",
     "sfm_ransac_batch_run_corr", "sfm_corr_destroy", "sfm_scale_chain", "sfm_scale_chain_refit",
+    "sfm_scale_chain_colors", "sfm_pixel_bilinear_u8",
     "sfm_match_batch_ratio", "sfm_match_batch_l2", "sfm_binset_create", "sfm_binset_destroy", "sfm_match_batch_hamming",
     "sfm_shard_count", "sfm_shard_indices", "sfm_shard_layout", "sfm_comm_unique_id", "sfm_comm_create",
     "sfm_comm_create_local", "sfm_comm_rank", "sfm_comm_destroy", "sfm_match_gather", "sfm_match_gather_local",
@@ -132,6 +133,8 @@ def lib() -> C.CDLL:
     L.sfm_corr_destroy.argtypes = [vp]
     L.sfm_scale_chain.argtypes = [vp, i32, vp, vp, vp, vp, vp, f64, i32, vp, vp, vp, vp]
     L.sfm_scale_chain_refit.argtypes = [vp, vp, vp, f64, i32, vp, vp, vp, vp]
+    L.sfm_scale_chain_colors.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, f64, i32, vp, vp, vp, vp, vp]
+    L.sfm_pixel_bilinear_u8.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     L.sfm_corr_destroy.restype = None
     if hasattr(L, "sfm_shard_count"):  # (absent only from older builds used in A/B timing runs)
         L.sfm_shard_count.argtypes = [i64, i32, i32]
@@ -578,6 +581,38 @@ class Context:
                                          _ptr(start_c), float(max_translation), int(n_tracks), _ptr(out[0]),
                                          _ptr(out[1]), _ptr(out[2]), _ptr(out[3])))
         return _chain_result(out, S, n_tracks)
+
+    def scale_chain_colors(self, offsets, track_ids, points, colors, poses, start_pose=None, max_translation=15.0, n_tracks=0):
+        """scale_chain with the running colour average of scene.cpp:394-407 (colors uint8 [total, 3]); the result
+        also holds colors [n_tracks, 3]."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        S = len(offsets) - 1
+        track_ids = np.ascontiguousarray(track_ids, np.int32)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        colors = np.ascontiguousarray(colors, np.uint8).reshape(-1, 3)
+        if len(colors) != len(points):
+            raise ValueError("one colour per point")
+        poses_c = np.ascontiguousarray(np.asarray(poses, np.float64).reshape(S, 4, 4).transpose(0, 2, 1))
+        start = np.eye(4) if start_pose is None else np.asarray(start_pose, np.float64)
+        start_c = np.ascontiguousarray(start.T)
+        out = _chain_outputs(S, n_tracks)
+        cols = np.zeros((max(n_tracks, 1), 3), np.uint8)
+        self.check(lib().sfm_scale_chain_colors(self._h, S, _ptr(offsets), _ptr(track_ids), _ptr(points), _ptr(colors),
+                                                _ptr(poses_c), _ptr(start_c), float(max_translation), int(n_tracks),
+                                                _ptr(out[0]), _ptr(out[1]), _ptr(cols), _ptr(out[2]), _ptr(out[3])))
+        res = _chain_result(out, S, n_tracks)
+        res["colors"] = cols[:n_tracks]
+        return res
+
+    def pixel_bilinear_u8(self, image_bgr, pixels):
+        """util::getPixelBilinearUchar (util.cpp:40-78) at every (u, v) of pixels: RGB uint8 [n, 3]."""
+        img = np.ascontiguousarray(image_bgr, np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("image must be rows x cols x 3 bytes")
+        px = np.ascontiguousarray(pixels, np.float64).reshape(-1, 2)
+        out = np.zeros((max(len(px), 1), 3), np.uint8)
+        self.check(lib().sfm_pixel_bilinear_u8(self._h, _ptr(img), img.shape[0], img.shape[1], _ptr(px), len(px), _ptr(out)))
+        return out[:len(px)]
 
     def eight_point_from_subset(self, calc1, calc2, all1, all2):
         """eightPointAlgorithmFromSubset (eightPoint.cpp:225-372): (pose 4x4, points [n_all,3])."""

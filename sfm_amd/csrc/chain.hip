@@ -10,7 +10,8 @@
 //                        exact median by radix selection on the ratios' bit patterns
 //   chain_walk_kernel    one lane: scale, view matrix, translation clamp, pose accumulation, step by step
 //   chain_points_kernel  one thread per track: walks the steps through the table and updates its mean
-// Geometry only; the colour average (scene.cpp:377, :394-407) needs the images.
+// The colour average (scene.cpp:394-407) runs beside the mean when the caller hands over the colour of every
+// observation (scene.cpp:377 samples it from the image: pixel_bilinear_kernel restates that sampler).
 //
 // Every floating-point operation is written in the order the CPU restatement uses (contraction off),
 // and the median is an exact selection, so the two agree bit for bit.
@@ -41,6 +42,8 @@ struct ChainArgs {
     double *points3d;   // [nTracks][3]
     int32_t *counts;    // [nTracks]
     double *accScale;   // [nSteps]
+    const unsigned char *colors; // optional [rows][3]: the colour of the observation behind every point
+    unsigned char *colors3d;     // [nTracks][3] running average of a track's colours (with colors)
     // work space
     int32_t *slot;      // [rows of the window][nTracks]: the point of a step that carries a track, or -1
     u64 *keys;          // per correspondence row: bit pattern of the point's depth ratio, 0 = none
@@ -283,12 +286,15 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_points_kernel(const Chain
     const int t = blockIdx.x * CHAIN_THREADS + threadIdx.x;
     if (t >= g.nTracks || g.error[0]) return;
     double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+    unsigned char col[3] = {0, 0, 0};
     int N = 0;
     if (g.s0 > 0) {
         m0 = g.points3d[3 * (size_t)t];
         m1 = g.points3d[3 * (size_t)t + 1];
         m2 = g.points3d[3 * (size_t)t + 2];
         N = g.counts[t];
+        if (g.colors)
+            for (int c = 0; c < 3; c++) col[c] = g.colors3d[3 * (size_t)t + c];
     }
     for (int s = g.s0; s < g.s1; s++) {
         const int k = slot_row(g, s)[t];
@@ -299,10 +305,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_points_kernel(const Chain
         const double scale = g.accScale[s];
         double gl[3];
         pose_apply(g.extrinsics + 16 * (size_t)s, scale * px, scale * py, scale * pz, gl);
+        const unsigned char *nc = g.colors ? g.colors + 3 * (size_t)(g.offsets[s] + k) : nullptr;
         if (N == 0) {
             m0 = gl[0];
             m1 = gl[1];
             m2 = gl[2];
+            if (nc)
+                for (int c = 0; c < 3; c++) col[c] = nc[c];
             N = 1;
         } else {
             const double d0 = m0 - gl[0], d1 = m1 - gl[1], d2 = m2 - gl[2];
@@ -311,6 +320,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_points_kernel(const Chain
                 m0 = m0 + (gl[0] - m0) / N1;
                 m1 = m1 + (gl[1] - m1) / N1;
                 m2 = m2 + (gl[2] - m2) / N1;
+                if (nc) { // scene.cpp:394-407: in float, clamped, cut off towards zero
+                    for (int c = 0; c < 3; c++) {
+                        const float cNew = (float)nc[c], cOld = (float)col[c];
+                        float res = cOld + (cNew - cOld) / (float)(N + 1);
+                        res = res < 0.f ? 0.f : (res > 255.f ? 255.f : res);
+                        col[c] = (unsigned char)res;
+                    }
+                }
                 N = N + 1;
             }
         }
@@ -319,17 +336,51 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_points_kernel(const Chain
     g.points3d[3 * (size_t)t + 1] = m1;
     g.points3d[3 * (size_t)t + 2] = m2;
     g.counts[t] = N;
+    if (g.colors)
+        for (int c = 0; c < 3; c++) g.colors3d[3 * (size_t)t + c] = col[c];
+}
+
+// util::getPixelBilinearUchar (util.cpp:40-78) for n positions of one image: BGR bytes in, RGB bytes out; the
+// weights and the weighted sum in double, in the reference's order; cv::saturate_cast<uchar>(double) rounds to
+// the nearest integer, ties to even, and clamps.
+__global__ __launch_bounds__(256) void pixel_bilinear_kernel(const unsigned char *__restrict__ bgr, int rows, int cols,
+                                                            const double2 *__restrict__ pixels, int n,
+                                                            unsigned char *__restrict__ rgb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double u = pixels[i].x, v = pixels[i].y;
+    const double fu = floor(u), fv = floor(v);
+    // (the cast of a value beyond int's range is undefined in the reference; here it saturates, and NaN goes to 0)
+    int x0 = fu >= 2147483647.0 ? 2147483647 : (fu <= -2147483648.0 ? (int)-2147483648ll : (int)fu);
+    int y0 = fv >= 2147483647.0 ? 2147483647 : (fv <= -2147483648.0 ? (int)-2147483648ll : (int)fv);
+    x0 = min(max(x0, 0), cols - 2);
+    y0 = min(max(y0, 0), rows - 2);
+    const double dx = u - x0, dy = v - y0;
+    const double w00 = (1.0 - dx) * (1.0 - dy), w10 = dx * (1.0 - dy), w01 = (1.0 - dx) * dy, w11 = dx * dy;
+    const unsigned char *p00 = bgr + 3 * ((size_t)y0 * cols + x0), *p10 = p00 + 3, *p01 = p00 + 3 * (size_t)cols, *p11 = p01 + 3;
+    unsigned char out[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double val = ((w00 * p00[c] + w10 * p10[c]) + w01 * p01[c]) + w11 * p11[c];
+        const double r = rint(val); // nearest, ties to even
+        out[c] = (unsigned char)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r)); // (NaN: 0)
+    }
+    rgb[3 * (size_t)i] = out[2]; // BGR -> RGB
+    rgb[3 * (size_t)i + 1] = out[1];
+    rgb[3 * (size_t)i + 2] = out[0];
 }
 
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
 struct ChainScratch {
-    DevBuf offsets, tracks, points, poses, extr, pts3d, counts, scale, slot, keys, rel, state;
+    DevBuf offsets, tracks, points, poses, extr, pts3d, counts, scale, slot, keys, rel, state, colors, cols3d, image, pixels;
     PinBuf err;
     void release()
     {
-        DevBuf *all[] = {&offsets, &tracks, &points, &poses, &extr, &pts3d, &counts, &scale, &slot, &keys, &rel, &state};
+        DevBuf *all[] = {&offsets, &tracks, &points, &poses, &extr, &pts3d, &counts, &scale, &slot, &keys, &rel, &state,
+                         &colors, &cols3d, &image, &pixels};
         for (DevBuf *d : all) d->release();
         err.release();
     }
@@ -351,7 +402,7 @@ static ChainScratch *chain_scratch(sfm_ctx *ctx)
 
 // Launches the four kernels window by window and fetches the outputs.  a: inputs filled in.
 static int chain_run(sfm_ctx *ctx, ChainScratch &w, ChainArgs &a, int64_t total, int maxStep, double *extrinsics_out,
-                     double *points3d_out, int32_t *counts_out, double *acc_scale_out)
+                     double *points3d_out, int32_t *counts_out, double *acc_scale_out, unsigned char *colors_out = nullptr)
 {
     hipStream_t st = ctx->stream;
     const size_t S = (size_t)a.nSteps, T = (size_t)a.nTracks;
@@ -361,6 +412,11 @@ static int chain_run(sfm_ctx *ctx, ChainScratch &w, ChainArgs &a, int64_t total,
     SFM_HIP(ctx, w.extr.reserve((S + 1) * 16 * sizeof(double)));
     SFM_HIP(ctx, w.pts3d.reserve((T ? T : 1) * 3 * sizeof(double)));
     SFM_HIP(ctx, w.counts.reserve((T ? T : 1) * sizeof(int32_t)));
+    if (a.colors) {
+        SFM_HIP(ctx, w.cols3d.reserve((T ? T : 1) * 3));
+        a.colors3d = w.cols3d.as<unsigned char>();
+        if (T) SFM_HIP(ctx, hipMemsetAsync(w.cols3d.p, 0, T * 3, ctx->stream));
+    }
     SFM_HIP(ctx, w.scale.reserve((S ? S : 1) * sizeof(double)));
     SFM_HIP(ctx, w.slot.reserve((size_t)(G + 1) * (T ? T : 1) * sizeof(int32_t)));
     SFM_HIP(ctx, w.keys.reserve((size_t)(total ? total : 1) * sizeof(u64)));
@@ -408,6 +464,7 @@ static int chain_run(sfm_ctx *ctx, ChainScratch &w, ChainArgs &a, int64_t total,
         SFM_HIP(ctx, hipMemcpyAsync(points3d_out, w.pts3d.p, T * 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (counts_out && T)
         SFM_HIP(ctx, hipMemcpyAsync(counts_out, w.counts.p, T * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (colors_out && a.colors && T) SFM_HIP(ctx, hipMemcpyAsync(colors_out, w.cols3d.p, T * 3, hipMemcpyDeviceToHost, st));
     if (acc_scale_out && S)
         SFM_HIP(ctx, hipMemcpyAsync(acc_scale_out, w.scale.p, S * sizeof(double), hipMemcpyDeviceToHost, st));
     SFM_HIP(ctx, hipStreamSynchronize(st));
@@ -434,10 +491,10 @@ static int chain_common_checks(sfm_ctx *ctx, int n_steps, const int64_t *offsets
     return SFM_OK;
 }
 
-extern "C" int sfm_scale_chain(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int32_t *track_ids,
-                               const double *points, const double *poses16, const double *start_pose16,
-                               double max_translation, int n_tracks, double *extrinsics_out, double *points3d_out,
-                               int32_t *counts_out, double *acc_scale_out)
+static int scale_chain_host(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int32_t *track_ids, const double *points,
+                            const unsigned char *colors, const double *poses16, const double *start_pose16, double max_translation,
+                            int n_tracks, double *extrinsics_out, double *points3d_out, unsigned char *colors_out,
+                            int32_t *counts_out, double *acc_scale_out)
 {
     if (!ctx) return SFM_ERR_INVALID_ARG;
     int rc = chain_common_checks(ctx, n_steps, offsets, start_pose16, max_translation, n_tracks);
@@ -455,10 +512,12 @@ extern "C" int sfm_scale_chain(sfm_ctx *ctx, int n_steps, const int64_t *offsets
     SFM_HIP(ctx, w.tracks.reserve((size_t)(total ? total : 1) * sizeof(int32_t)));
     SFM_HIP(ctx, w.points.reserve((size_t)(total ? total : 1) * 3 * sizeof(double)));
     SFM_HIP(ctx, w.poses.reserve((S ? S : 1) * 16 * sizeof(double)));
+    if (colors) SFM_HIP(ctx, w.colors.reserve((size_t)(total ? total : 1) * 3));
     if (S) SFM_HIP(ctx, hipMemcpyAsync(w.offsets.p, offsets, (S + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st));
     if (total) {
         SFM_HIP(ctx, hipMemcpyAsync(w.tracks.p, track_ids, (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice, st));
         SFM_HIP(ctx, hipMemcpyAsync(w.points.p, points, (size_t)total * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+        if (colors) SFM_HIP(ctx, hipMemcpyAsync(w.colors.p, colors, (size_t)total * 3, hipMemcpyHostToDevice, st));
     }
     if (S) SFM_HIP(ctx, hipMemcpyAsync(w.poses.p, poses16, S * 16 * sizeof(double), hipMemcpyHostToDevice, st));
     int maxStep = 0;
@@ -470,9 +529,58 @@ extern "C" int sfm_scale_chain(sfm_ctx *ctx, int n_steps, const int64_t *offsets
     a.tracks = w.tracks.as<int32_t>();
     a.points = w.points.as<double>();
     a.poses = w.poses.as<double>();
+    a.colors = colors ? w.colors.as<unsigned char>() : nullptr;
     a.maxTranslation = max_translation;
     memcpy(a.start, start_pose16, sizeof a.start);
-    return chain_run(ctx, w, a, total, maxStep, extrinsics_out, points3d_out, counts_out, acc_scale_out);
+    return chain_run(ctx, w, a, total, maxStep, extrinsics_out, points3d_out, counts_out, acc_scale_out, colors_out);
+}
+
+extern "C" int sfm_scale_chain(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int32_t *track_ids,
+                               const double *points, const double *poses16, const double *start_pose16,
+                               double max_translation, int n_tracks, double *extrinsics_out, double *points3d_out,
+                               int32_t *counts_out, double *acc_scale_out)
+{
+    return scale_chain_host(ctx, n_steps, offsets, track_ids, points, nullptr, poses16, start_pose16, max_translation, n_tracks,
+                            extrinsics_out, points3d_out, nullptr, counts_out, acc_scale_out);
+}
+
+extern "C" int sfm_scale_chain_colors(sfm_ctx *ctx, int n_steps, const int64_t *offsets, const int32_t *track_ids,
+                                      const double *points, const uint8_t *colors, const double *poses16,
+                                      const double *start_pose16, double max_translation, int n_tracks,
+                                      double *extrinsics_out, double *points3d_out, uint8_t *colors_out,
+                                      int32_t *counts_out, double *acc_scale_out)
+{
+    if (ctx && n_steps > 0 && offsets && offsets[n_steps] > 0 && !colors)
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "scale chain: null colours");
+    static const uint8_t none[3] = {0, 0, 0}; // (no observation at all: the colour path still clears its output)
+    return scale_chain_host(ctx, n_steps, offsets, track_ids, points, colors ? colors : none, poses16, start_pose16, max_translation,
+                            n_tracks, extrinsics_out, points3d_out, colors_out, counts_out, acc_scale_out);
+}
+
+extern "C" int sfm_pixel_bilinear_u8(sfm_ctx *ctx, const uint8_t *bgr, int rows, int cols, const double *pixels, int n,
+                                     uint8_t *rgb_out)
+{
+    if (!ctx) return SFM_ERR_INVALID_ARG;
+    if (n < 0 || rows < 2 || cols < 2 || !bgr || (n > 0 && (!pixels || !rgb_out)))
+        SFM_FAIL(ctx, SFM_ERR_INVALID_ARG, "pixel_bilinear: an image of at least 2 x 2 pixels, positions and an output are needed");
+    if (n == 0) return SFM_OK;
+    SFM_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ChainScratch *wp = chain_scratch(ctx);
+    if (!wp) SFM_FAIL(ctx, SFM_ERR_OOM, "pixel_bilinear: host allocation failed");
+    ChainScratch &w = *wp;
+    const size_t imgBytes = (size_t)rows * cols * 3;
+    SFM_HIP(ctx, w.image.reserve(imgBytes));
+    SFM_HIP(ctx, w.pixels.reserve((size_t)n * sizeof(double2)));
+    SFM_HIP(ctx, w.colors.reserve((size_t)n * 3));
+    SFM_HIP(ctx, hipMemcpyAsync(w.image.p, bgr, imgBytes, hipMemcpyHostToDevice, st));
+    SFM_HIP(ctx, hipMemcpyAsync(w.pixels.p, pixels, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pixel_bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.image.as<unsigned char>(), rows,
+                       cols, w.pixels.as<double2>(), n, w.colors.as<unsigned char>());
+    SFM_HIP(ctx, hipGetLastError());
+    SFM_HIP(ctx, hipMemcpyAsync(rgb_out, w.colors.p, (size_t)n * 3, hipMemcpyDeviceToHost, st));
+    SFM_HIP(ctx, hipStreamSynchronize(st));
+    return SFM_OK;
 }
 
 extern "C" int sfm_scale_chain_refit(sfm_ransac_batch *b, const int32_t *corr_track_ids, const double *start_pose16,

@@ -180,3 +180,43 @@ def test_chain_on_refitted_batch(ctx, oracle):
     batch2 = corr.ransac(K, 64, 5, max_sq_err=1.0, success_prob=0.999, adaptive=True)
     with pytest.raises(capi.SfmError, match="refit"):
         batch2.scale_chain(corr_ids, n_tracks=n_tracks)
+
+
+@pytest.mark.parametrize("seed,n_steps,n_tracks,entries", [(11, 26, 1500, 1 << 26), (12, 9, 300, 1 << 26), (13, 11, 700, 3 * 700)])
+def test_chain_with_colours_matches_restatement(ctx, oracle, seed, n_steps, n_tracks, entries):
+    """The running colour average beside the point mean (scene.cpp:377, :394-407): per channel in float, clamped, cut
+    off towards zero, updated exactly when the mean is.  Bit-exact, also when the steps go through in windows
+    (the colours are carried from window to window like the means)."""
+    off, ids, pts, poses = sequence(seed, n_steps, n_tracks, behind=0.1)
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, 256, (len(ids), 3), dtype=np.uint8)
+    cols[rng.random(len(ids)) < 0.1] = 255
+    cols[rng.random(len(ids)) < 0.1] = 0
+    exp = oracle.scale_chain_colors(off, ids, pts, cols, poses, n_tracks=n_tracks)
+    ctx.set_option("chain_table_entries", entries)
+    try:
+        got = ctx.scale_chain_colors(off, ids, pts, cols, poses, n_tracks=n_tracks)
+    finally:
+        ctx.set_option("chain_table_entries", 1 << 26)
+    same(got, exp, f"seed {seed}")
+    assert np.array_equal(got["colors"], exp["colors"])
+    assert (got["counts"] > 2).sum() > n_tracks // 8 and got["colors"].any()
+    # the geometry does not depend on the colours
+    same(got, ctx.scale_chain(off, ids, pts, poses, n_tracks=n_tracks), "with and without colours")
+
+
+def test_pixel_bilinear_matches_restatement(ctx, oracle):
+    """util::getPixelBilinearUchar (util.cpp:40-78) for many positions of one image: inside, on pixel centres, on the
+    borders and outside (the first neighbour is clamped into the image, the weights are not: the reference
+    extrapolates), values that round half-way."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    px = np.concatenate([rng.uniform([-5, -5], [136, 102], (5000, 2)),
+                         np.stack([rng.integers(0, 131, 500), rng.integers(0, 97, 500)], axis=1).astype(np.float64),
+                         np.stack([rng.integers(0, 130, 500) + 0.5, rng.integers(0, 96, 500) + 0.5], axis=1),
+                         np.array([[0.0, 0.0], [130.0, 96.0], [129.999, 95.999], [-1e9, 1e9], [1e300, -1e300]])])
+    got = ctx.pixel_bilinear_u8(img, px)
+    exp = oracle.pixel_bilinear_u8(img, px[:-1])  # (the cast of 1e300 to int is undefined on the CPU)
+    assert np.array_equal(got[:-1], exp)
+    with pytest.raises(capi.SfmError):
+        ctx.pixel_bilinear_u8(np.zeros((1, 5, 3), np.uint8), px[:3])

@@ -615,3 +615,32 @@ def test_match_hamming_by_hand(oracle):
     pB[3] = [10, 0]  # the gate hides column 3: row 2 falls back to its twin
     pairs, _, _ = oracle.match_hamming(A, pA, B, pB, max_distance=2, max_dist_sq=1.0)
     assert pairs.tolist() == [[0, 0], [1, 2], [2, 4]]
+
+
+def test_colour_average_by_hand(oracle):
+    """scene.cpp:394-407 on one track seen three times: 10 -> 10 + (20 - 10) / 2 = 15 -> 15 + (16 - 15) / 3 = 15.33 -> 15
+    (cut off); 250 then 255 twice: 252.5 -> 252 -> 252 + 3 / 3 = 253; a sighting farther than 50 from the mean
+    changes neither the mean nor the colour."""
+    off = np.array([0, 1, 2, 3, 4])
+    ids = np.zeros(4, np.int32)
+    pts = np.array([[0, 0, 5.0], [0, 0, 5.0], [0, 0, 500.0], [0, 0, 5.0]])
+    poses = np.tile(np.eye(4), (4, 1, 1))
+    cols = np.array([[10, 250, 0], [20, 255, 1], [200, 0, 99], [16, 255, 2]], np.uint8)
+    r = oracle.scale_chain_colors(off, ids, pts, cols, poses, n_tracks=1)
+    assert r["counts"][0] == 3
+    assert r["colors"][0].tolist() == [15, 253, 0]  # (third channel: 0 -> 0.5, cut off to 0 -> 0 + 2 / 3, cut off to 0)
+    assert np.array_equal(r["points3d"][0], [0.0, 0.0, 5.0])
+
+
+def test_pixel_bilinear_by_hand(oracle):
+    """util.cpp:40-78: BGR in, RGB out; weights from the clamped first neighbour; nearest integer, ties to even."""
+    img = np.zeros((3, 3, 3), np.uint8)
+    img[0, 0] = [10, 20, 30]
+    img[0, 1] = [11, 20, 40]
+    img[1, 0] = [10, 21, 50]
+    img[1, 1] = [11, 21, 60]
+    got = oracle.pixel_bilinear_u8(img, [[0, 0], [0.5, 0.5], [0.5, 0.0], [1, 1]])
+    assert got[0].tolist() == [30, 20, 10]
+    assert got[1].tolist() == [45, 20, 10]  # 45; 20.5 -> 20 (ties to even); 10.5 -> 10
+    assert got[2].tolist() == [35, 20, 10]  # 35; 20; 10.5 -> 10
+    assert got[3].tolist() == [60, 21, 11]
