@@ -433,8 +433,8 @@ void sfm_corr_destroy(sfm_corr *c);
 
 /* ---- scale chaining and running point average ------------------------------
  * Replaces the tail of Scene::solveForLastAddedFrame, scene.cpp:301-421, for a
- * whole sequence at once (geometry only; the colour average of scene.cpp:377,
- * :394-407 needs the images).  Step s joins frames s and s + 1 and brings the
+ * whole sequence at once (sfm_scale_chain: geometry only; sfm_scale_chain_colors
+ * adds the colour average of scene.cpp:377, :394-407).  Step s joins frames s and s + 1 and brings the
  * two-view solution of that pair: pose (column-major 4x4, m_frame23.pose), the
  * triangulated points in the older camera's frame (m_frame23.points) and the
  * track id of each point (m_trackIndices23), distinct inside a step (the
