@@ -325,6 +325,14 @@ def main():
                       "ransac_hyps_per_s": out.get("ransac", {}).get("value"),
                       "cpu_pairs_per_s": out.get("cpu_baseline", {}).get("value"),
                       "cpu_ransac_hyps_per_s": out.get("cpu_baseline", {}).get("ransac", {}).get("value")}
+    for r in out.get("ransac", {}).get("where_a_model_is_found", []):  # batches of 256 pairs where a model exists, pre-test on
+        if r.get("pre_test"):
+            tag = f"ransac_at_{int(round(100 * r['inlier_ratio']))}pct_inliers"
+            out["summary"][tag] = {"pairs_per_s_scan_stopped_by_the_cap": r["adaptive_stop"]["pairs_per_s"],
+                                   "hyps_per_s_every_row_scored": r["all_rows_scored"]["hyps_per_s"]}
+    for r in out.get("regimes", []):
+        if r.get("threshold") == 0.5 and "pairs_per_s" in r and "pairs_per_s_at_the_reference_default_threshold" not in out["summary"]:
+            out["summary"]["pairs_per_s_at_the_reference_default_threshold"] = r["pairs_per_s"]
     if rank == 0:
         sys.stdout.flush()
         line = (json.dumps(out) + "\n").encode()
