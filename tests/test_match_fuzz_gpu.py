@@ -70,12 +70,17 @@ def test_random_batch(ctx, oracle, seed):
     gate = float(rng.choice([1e8, 120.0 ** 2]))
     as_bytes = bool(rng.integers(2))
     ctx.set_option("pairs_per_launch", int(rng.choice([1, 3, 2048])))
+    ctx.set_option("match_list_observe", int(rng.choice([0, 1, 2, 2])))  # (2: calls of nine chunks and more size their lists as they go)
     try:
         s = ctx.imageset(counts, desc.astype(np.uint8) if as_bytes else desc, pts)
         res = s.match(pl, threshold=thr, max_dist_sq=gate)
         off, pairs = res.offsets(), res.pairs()
+        if rng.random() < 0.5:  # the same call again on the same result object (its buffers are kept)
+            res = s.match(pl, threshold=thr, max_dist_sq=gate, result=res)
+            assert np.array_equal(off, res.offsets()) and np.array_equal(pairs, res.pairs())
     finally:
         ctx.set_option("pairs_per_launch", 2048)
+        ctx.set_option("match_list_observe", 1)
     starts = np.concatenate([[0], np.cumsum(counts)])
     assert off[0] == 0 and off[-1] == len(pairs)
     for k, (a, b) in enumerate(pl):
