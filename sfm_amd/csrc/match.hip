@@ -1119,7 +1119,7 @@ template <bool CLEAR> __global__ __launch_bounds__(256) void match_col_bars_kern
 // only: every path gives the same lists.  (Cosine only: an L2 pair that overflows is scored cell by cell, far
 // too dear for a guess.)
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void match_flood_probe_kernel(const MatchArgs g)
+__global__ __launch_bounds__(1024) void match_flood_probe_kernel(const MatchArgs g)
 {
     __shared__ int total;
     const int p = blockIdx.x;
@@ -1135,8 +1135,8 @@ __global__ __launch_bounds__(256) void match_flood_probe_kernel(const MatchArgs 
 #pragma unroll
     for (int q = 0; q < KDIM / 2; q++) ar[q] = a[q];
     int hits = 0;
-    for (int k = 0; k < 64; k++) {
-        const int j = (int)(((int64_t)(cg * 64 + k) * pr.nB) >> 8);
+    for (int k = 0; k < 16; k++) { // sixteen groups of 64 threads: 16 of the 256 columns each
+        const int j = (int)(((int64_t)(cg * 16 + k) * pr.nB) >> 8);
         const half2v *b = reinterpret_cast<const half2v *>(g.desc16 + (size_t)(pr.rowB16 + j) * KDIM);
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
@@ -1161,14 +1161,14 @@ __global__ __launch_bounds__(256) void match_flood_probe_kernel(const MatchArgs 
 
 // In place of an int8 strict pass that is known to flood (see the chunk loop): every pair with work gets the flag
 // such a pass would have left.
-__global__ __launch_bounds__(256) void match_flag_flooded_kernel(const MatchArgs g, int np)
+__global__ __launch_bounds__(256) void match_flag_flooded_kernel(const MatchArgs g, int np, int flag)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= np) return;
     const PairRec pr = g.pairs[p];
     if (pr.nA <= 0 || pr.nB <= 0) return;
-    g.pairOvf[p] = 3;
-    if (g.flagCount[3] == 0) g.flagCount[3] = 1; // (only zero / non-zero matters)
+    g.pairOvf[p] = flag;
+    if (g.flagCount[flag] == 0) g.flagCount[flag] = 1; // (only zero / non-zero matters)
 }
 
 // One work item per block: the pass every pair takes.
@@ -1447,6 +1447,7 @@ __global__ __launch_bounds__(256) void match_overflow_list_kernel(const MatchArg
     if (threadIdx.x == 0) {
         g.ovfList[0] = n;
         if (n) atomicAdd(&g.stats[1], (u64)n);
+        if (g.flagOut) *g.flagOut = nPairs > 0 ? g.pairOvf[0] : 0; // (no later pass changes a flag)
     }
 }
 
@@ -2030,6 +2031,14 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         packedPairs = reinterpret_cast<int2 *>(packed + 16 + bests);
         res->packedBytes = 16 + bests; // up to the list
     }
+    int pairGuessFrom = 0; // single-pair calls: the flag of the call before with the same options (0: none, or time to look again)
+    if (want_m1m2) {
+        if (memcmp(&res->pairKey, &key, sizeof key) == 0 && (++res->pairCalls & 15u) != 0) pairGuessFrom = res->pairFlag;
+        else res->pairCalls = memcmp(&res->pairKey, &key, sizeof key) == 0 ? res->pairCalls : 0;
+        memset(&res->pairKey, 0, sizeof res->pairKey);
+        res->pairKey = key;
+        res->pairFlag = 0; // (until this call's flag has been read)
+    }
     hipStream_t st = ctx->stream;
     if (n_pairs == 0) SFM_HIP(ctx, clear_ranges(st, {{res->offsets.p, sizeof(int64_t)}, {res->stats.p, 4 * sizeof(u64)}}));
     if (overlap) { // the other two streams start where the first one stands
@@ -2039,6 +2048,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     }
 
     MatchArgs g;
+    g.flagOut = packed ? reinterpret_cast<int *>(packed + 8) : nullptr;
     g.desc16 = set->desc16.as<_Float16>();
     g.desc8 = set->desc8.as<signed char>();
     g.desc8u = set->u8_exact ? set->desc8u.as<unsigned char>() : nullptr;
@@ -2158,12 +2168,18 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             // later chunks (and later calls with the same options) start where a flooded int8 pass would leave them
             // -- every pair flagged for the probe below, which still decides pair by pair between the fp16 strict
             // pass and the filtered ones.  A wrong guess costs time only: all paths give the same lists.
-            const bool skipInt8 = res->floodObserved && !probe && variant.strict16 && ctx->match_flood_probe &&
-                                  metric == SFM_METRIC_COSINE && ratio == 0.0f;
+            // A single-pair call (the reference's pattern: frame after frame with the same options) remembers the flag
+            // its pair ended with: after a call whose int8 lists flooded the next one starts where that one ended up --
+            // at the probe (flag 3), or, when the fp16 lists flooded too, at the filtered passes (flag 1: no probe
+            // either) -- except every sixteenth call, which takes the whole way again to see whether it still holds.
+            const bool guessable = variant.strict16 && ctx->match_flood_probe && metric == SFM_METRIC_COSINE && ratio == 0.0f;
+            const int pairGuess = (want_m1m2 && guessable && pairGuessFrom && twoPhase) ? (pairGuessFrom == 3 ? 3 : 1) : 0;
+            const bool skipInt8 = pairGuess != 0 || (res->floodObserved && !probe && guessable);
             if (strictFirst) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
-                if (skipInt8) hipLaunchKernelGGL(match_flag_flooded_kernel, dim3((np + 255) / 256), dim3(256), 0, st, g, np);
+                if (skipInt8)
+                    hipLaunchKernelGGL(match_flag_flooded_kernel, dim3((np + 255) / 256), dim3(256), 0, st, g, np, pairGuess ? pairGuess : 3);
                 else hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
                 SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
                 // The first bound passes of consecutive chunks follow each other on this stream (each fills the
@@ -2182,8 +2198,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 if (rc != SFM_OK) return rc;
             }
             if (strictFirst && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
-                if (ctx->match_flood_probe && metric == SFM_METRIC_COSINE)
-                    hipLaunchKernelGGL(match_flood_probe_kernel, dim3(np), dim3(256), 0, st, g);
+                if (ctx->match_flood_probe && metric == SFM_METRIC_COSINE && pairGuess != 1)
+                    hipLaunchKernelGGL(match_flood_probe_kernel, dim3(np), dim3(1024), 0, st, g);
                 g.onlyFlagged = 3;
                 g.nWork = nblk;
                 hipLaunchKernelGGL(variant.strict16, dim3(std::min(nblk, walk_grid(3))), dim3(SIM_WAVES * 64), 0, st, g);
@@ -2520,6 +2536,7 @@ static int match_pair_impl(sfm_ctx *ctx, int algorithm, const void *descA, const
     const size_t b1 = matches1_out ? (size_t)nA * sizeof(int32_t) : 0, b2 = matches2_out ? (size_t)nB * sizeof(int32_t) : 0;
     int64_t total = 0;
     memcpy(&total, stage, sizeof total);
+    memcpy(&res->pairFlag, stage + 8, sizeof(int)); // the flag the pair ended with: where the next call starts
     res->total = total;
     if (total > capacity) SFM_FAIL(ctx, SFM_ERR_CAPACITY, "match: output capacity too small");
     if (total > 0) {

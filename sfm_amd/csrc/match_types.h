@@ -39,6 +39,7 @@ struct MatchArgs {
     int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
     int *pairOvf;         // [pairs in chunk]: a slice overflowed in 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
     int *flagCount;       // [4]: how often a flag value was set in this chunk (only zero / non-zero matters)
+    int *flagOut;         // single-pair calls: where the pair's final flag goes (beside the packed count), or null
     int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
     int nWork;            // entries of the work list (passes that walk it)
     int orient;           // filtered passes: 0 = image A's rows stay in registers, 1 = image B's
@@ -117,6 +118,10 @@ struct sfm_match_result {
     PinBuf hostTotals;
     hipEvent_t listEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> retired;
+    // single-pair calls: the flag the last call's pair ended with (see pairOvf), for which options, and calls so far
+    int pairFlag = 0;
+    MatchKey pairKey = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};
+    unsigned pairCalls = 0;
 };
 int sfm_match_result_mark_done(sfm_ctx *ctx, sfm_match_result *res);
 

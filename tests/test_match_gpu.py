@@ -745,3 +745,23 @@ def test_lists_sized_as_the_call_goes_are_the_same_lists(ctx, threshold):
     assert bytes2 == bytes1 and bytes1 < bytes0  # (at threshold 0.5 most keypoints find a partner: little to save)
     if threshold > 0.9:
         assert bytes0 - bytes1 > worst // 3
+
+
+def test_single_pair_calls_remember_where_the_last_one_ended(ctx, oracle):
+    """Single-pair calls at the reference's default threshold (match.hpp:59), one after the other as the reference
+    makes them (scene.cpp:60): a call starts where the call before ended up (past the int8 attempt, or straight at
+    the filtered passes) and takes the whole way again every sixteenth time.  Pairs whose lists flood and pairs
+    whose lists do not alternate in blocks, so that every guess is wrong some of the time: the lists are the
+    restatement's every time."""
+    n = 1100
+    sets = []
+    for kind, seed in (("sift", 41), ("gauss", 42)):
+        d, p, _ = synth.image_set(2, n, seed=seed, kind=kind)
+        exp, m1, m2 = oracle.match(d[:n], p[:n], d[n:], p[n:], threshold=0.5, max_dist_sq=1e8)
+        sets.append((d, p, exp, m1, m2))
+    order = [0] * 5 + [1] * 3 + [0] * 20 + [1] * 7 + [0, 1] * 6
+    for k, which in enumerate(order):
+        d, p, exp, m1, m2 = sets[which]
+        got = ctx.match_pair(d[:n], p[:n], d[n:], p[n:], threshold=0.5, max_dist_sq=1e8, return_best=True)
+        assert np.array_equal(got[0], exp), (k, which)
+        assert np.array_equal(got[1], m1) and np.array_equal(got[2], m2), (k, which)
