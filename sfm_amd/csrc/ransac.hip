@@ -3193,10 +3193,13 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
         // evaluated in full, and every slice after it ends with the device running empty once (measured on 256
         // pairs of 20000 correspondences: at 80 % inliers the smaller slice is worth a third of the time, at
         // 15 % the larger one a twentieth).
-        // (a batch that is one round of blocks in all keeps the old first slice, i.e. stays whole: two halves would
-        // each leave half of the device idle for as long as a wave takes)
-        const bool oneRound = (int64_t)n_pairs * ((n_hyp + 255) / 256) <= 4 * (int64_t)ctx->n_cus;
-        const int64_t fill = ((defer && !oneRound) ? (adaptive ? 2 : 4) : 8) * (int64_t)ctx->n_cus;
+        // Small batches (measured on 64 and 16 pairs): one that is at most a round of blocks in all takes a block
+        // per CU first (64 pairs: 3.6 / 2.6 / 1.3 ms at 80 / 50 / 15 % inliers against 8.5 / 1.5 / 1.0 ms in one
+        // slice); one of at most a block per CU stays whole, as before.
+        const int64_t blocksInAll = (int64_t)n_pairs * ((n_hyp + 255) / 256);
+        const int64_t fill = (!defer || blocksInAll <= ctx->n_cus) ? 8 * (int64_t)ctx->n_cus
+                             : blocksInAll <= 4 * (int64_t)ctx->n_cus ? (int64_t)ctx->n_cus
+                                                                      : (adaptive ? 2 : 4) * (int64_t)ctx->n_cus;
         int64_t h = 256 * std::max<int64_t>(1, (fill + n_pairs - 1) / n_pairs);
         if (!no_alloc && split_factor(ctx, n_pairs, 256, total) > 1 && (size_t)total * 256 * sizeof(double) <= ((size_t)1 << 30)) h = 256;
         if (ctx->hyps_per_launch > 0) h = 64 * ((ctx->hyps_per_launch + 63) / 64); // caller's first slice
