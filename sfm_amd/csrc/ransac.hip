@@ -67,6 +67,7 @@ struct RansacArgs {
     unsigned int *candUb;     // [candMax] cells of the row that pass the packed test: an upper bound of its count
     long long *heavyRow;      // [heavyMax] pair << 32 | row of the slot
     double *heavyErr;         // [heavyMax][heavyStride] error of the cell where it is an inlier's, else -1
+    signed char *rowMark;     // [P][H] 0, ROW_HANDED or ROW_PASSED for the rows of the current slice
     int candMax, heavyMax, heavyStride;
     int heavyBound;           // 1: candUb is made for this slice, and rows whose bound is below the pair's best count are passed over
     uint4 *mfOps; // the correspondence side of that test, made once per call (see mfma_ops_start), or NULL: the
@@ -1294,7 +1295,7 @@ extern "C" int sfm_debug_wave_stats(unsigned long long *out)
 #endif
 // DEFER: rows with many inliers hold a wave up -- their cells are evaluated 64 at a time by a wave whose other
 // rows have long been done, and at the end of a launch a few such waves keep the device waiting.  Such rows are
-// dealt with beforehand (ransac_heavy_find_kernel and the kernels after it) and marked in the count array:
+// dealt with beforehand (ransac_heavy_find_kernel and the kernels after it) and marked (rowMark):
 // ROW_HANDED rows are evaluated cell by cell after this kernel (ransac_heavy_eval_kernel, ransac_heavy_sum_kernel),
 // ROW_PASSED rows cannot matter to the scan and stay at count 0.  Neither gets operands here, so none of their
 // cells passes the test; the sums of ROW_HANDED rows are not written.
@@ -1380,7 +1381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
     bool ownHanded = false, ownPassed = false;
     if constexpr (DEFER) {
         if (defer_applies(g, p, n) && lane < nRowsW) {
-            const int mark = g.counts[(size_t)p * g.H + rowW0 + lane];
+            const int mark = g.rowMark[(size_t)p * g.H + rowW0 + lane];
             ownHanded = mark == ROW_HANDED;
             ownPassed = mark == ROW_PASSED;
         }
@@ -1735,7 +1736,7 @@ __global__ __launch_bounds__(256) void ransac_heavy_find_kernel(const RansacArgs
             g.candUb[mineAt] = 0u;
         }
     }
-    if (inPlay) g.counts[(size_t)p * g.H + rowW0 + spokenRow] = 0;
+    if (inPlay) g.rowMark[(size_t)p * g.H + rowW0 + spokenRow] = 0;
 }
 
 // The cells of a candidate row that pass the packed fp32 test of ransac_score_kernel (a cell that fails it lies
@@ -1833,7 +1834,7 @@ __global__ __launch_bounds__(256) void ransac_heavy_assign_kernel(const RansacAr
                 mark = ROW_HANDED;
             }
         }
-        if (mark) g.counts[(size_t)p * g.H + row] = mark;
+        if (mark) g.rowMark[(size_t)p * g.H + row] = (signed char)mark;
         // (tallies of the call, for sfm_ransac_batch_handed_over: a wave adds up its lanes)
         const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
         const unsigned long long pa = __builtin_amdgcn_ballot_w64(mark == ROW_PASSED), ha = __builtin_amdgcn_ballot_w64(mark == ROW_HANDED);
@@ -2885,7 +2886,7 @@ struct sfm_ransac_batch {
     int64_t total = 0;
     DevBuf x, y, samples, corrOff, rec, pose12, counts, toterr, bestH, bestCount, bestErr, iterations, inlCount,
         inlOff, inliers, refitPose, refitUsed, refitPoints, active, maxIter, errBuf, rec32, mfOps, inlFlag, inlBlk, clock, packed,
-        heavyCount, heavyRow, heavyErr, candRow, candUb;
+        heavyCount, heavyRow, heavyErr, candRow, candUb, rowMark;
     PinBuf stage;   // single-pair calls: the winner's record and its inlier list in one copy
     PinBuf stageIn; // and the two correspondence arrays on their way in
     RansacArgs args;       // of the last run (device pointers; x, y may belong to the caller)
@@ -2906,7 +2907,7 @@ extern "C" void sfm_ransac_batch_destroy(sfm_ransac_batch *b)
     DevBuf *bufs[] = {&b->x, &b->y, &b->samples, &b->corrOff, &b->rec, &b->pose12, &b->counts, &b->toterr,
                       &b->bestH, &b->bestCount, &b->bestErr, &b->iterations, &b->inlCount, &b->inlOff, &b->inliers,
                       &b->refitPose, &b->refitUsed, &b->refitPoints, &b->active, &b->maxIter, &b->errBuf, &b->rec32, &b->mfOps, &b->inlFlag, &b->inlBlk,
-                      &b->clock, &b->packed, &b->heavyCount, &b->heavyRow, &b->heavyErr, &b->candRow, &b->candUb};
+                      &b->clock, &b->packed, &b->heavyCount, &b->heavyRow, &b->heavyErr, &b->candRow, &b->candUb, &b->rowMark};
     for (DevBuf *d : bufs) d->release();
     b->stage.release();
     b->stageIn.release();
@@ -3162,6 +3163,8 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
             SFM_HIP(ctx, hipMemsetAsync(b->heavyCount.p, 0, 8 * sizeof(unsigned int), st));
             SFM_HIP(ctx, b->candRow.reserve((size_t)cands * sizeof(long long)));
             SFM_HIP(ctx, b->candUb.reserve((size_t)cands * sizeof(unsigned int)));
+            SFM_HIP(ctx, b->rowMark.reserve(PH));
+            g.rowMark = b->rowMark.as<signed char>();
             if (!b->side) {
                 SFM_HIP(ctx, hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
                 SFM_HIP(ctx, hipEventCreateWithFlags(&b->sideGo, hipEventDisableTiming));
