@@ -1885,19 +1885,24 @@ __global__ __launch_bounds__(256) void ransac_heavy_eval_kernel(const RansacArgs
     }
 }
 
-// Count and error sum of the rows handed over, in correspondence order (RANSAC.cpp:207-221): 64 rows per block,
-// all waves bring tiles of 64 correspondences x 64 rows into LDS, the first wave adds a tile up, a lane per
-// row, while the next one is on its way (a cell that is no inlier adds -0.0, which changes no sum).
-__global__ __launch_bounds__(256) void ransac_heavy_sum_kernel(const RansacArgs g)
+// Count and error sum of the rows handed over, in correspondence order (RANSAC.cpp:207-221).  The additions of a
+// row form one dependent chain of as many links as the pair has correspondences, so what counts is how fast a
+// chain advances, not how many run: a wave takes 16 rows and nothing but its own pace -- all 64 lanes fetch tiles of
+// 64 correspondences x 16 rows (the next tile is on its way while this one is added up) and put them through the
+// wave's LDS transposed, telling inliers from the rest and counting them as they go (a cell that is no inlier goes in
+// as -0.0, which changes no sum); lanes 0..15 then add a row each, one LDS read and one addition per cell, sixteen
+// reads ahead.  No barrier between waves.
+#define HSUM_ROWS 16
+__global__ __launch_bounds__(64) void ransac_heavy_sum_kernel(const RansacArgs g)
 {
-    __shared__ double tile[2][64][65];
-    __shared__ int sN[64], sP[64], sRow[64];
+    __shared__ double tile[2][64][HSUM_ROWS + 1];
+    __shared__ int sN[HSUM_ROWS], sP[HSUM_ROWS], sRow[HSUM_ROWS], cnts[HSUM_ROWS];
     const int used = (int)min(g.heavyCount[1], (unsigned)g.heavyMax);
-    const int slot0 = blockIdx.x * 64;
+    const int slot0 = blockIdx.x * HSUM_ROWS;
     if (slot0 >= used) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 64) {
-        const int slot = slot0 + tid;
+    const int lane = threadIdx.x;
+    if (lane < HSUM_ROWS) {
+        const int slot = slot0 + lane;
         int n = 0, p = -1, row = 0;
         if (slot < used) {
             const long long hr = g.heavyRow[slot];
@@ -1905,43 +1910,40 @@ __global__ __launch_bounds__(256) void ransac_heavy_sum_kernel(const RansacArgs 
             row = (int)(hr & 0xFFFFFFFFll);
             n = (int)(g.corrOff[p + 1] - g.corrOff[p]);
         }
-        sN[tid] = n;
-        sP[tid] = p;
-        sRow[tid] = row;
+        sN[lane] = n;
+        sP[lane] = p;
+        sRow[lane] = row;
     }
-    __syncthreads();
-    int nMax = 0;
-    for (int i = 0; i < 64; i++) nMax = max(nMax, sN[i]);
-    int myN[16];
+    __syncthreads(); // (one wave: orders the LDS writes above before the reads below)
+    int nMax = 0, myN[HSUM_ROWS];
 #pragma unroll
-    for (int j = 0; j < 16; j++) myN[j] = sN[wave * 16 + j];
-    const double *src = g.heavyErr + (size_t)(slot0 + wave * 16) * g.heavyStride + lane;
-    double regs[16];
-    auto fetch = [&](int k0) __attribute__((always_inline)) {
+    for (int j = 0; j < HSUM_ROWS; j++) {
+        myN[j] = sN[j];
+        nMax = max(nMax, myN[j]);
+    }
+    const double *src = g.heavyErr + (size_t)slot0 * g.heavyStride + lane;
+    constexpr int DEPTH = 3; // tiles on their way: a fetch takes several times as long as a tile's additions
+    double regs[DEPTH][HSUM_ROWS];
+    auto fetch = [&](double (&r)[HSUM_ROWS], int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) regs[j] = (k0 + lane < myN[j]) ? src[(size_t)j * g.heavyStride + k0] : -1.0;
+        for (int j = 0; j < HSUM_ROWS; j++) r[j] = (k0 + lane < myN[j]) ? src[(size_t)j * g.heavyStride + k0] : -1.0;
     };
-    // Only the additions of a row depend on each other.  Telling inliers from the rest and counting them is done by
-    // the threads that fetch: a cell that is no inlier goes into the tile as -0.0, so the chain is one LDS read and
-    // one addition per cell.
-    __shared__ int cnts[64];
-    if (tid < 64) cnts[tid] = 0;
-    int cnt[16];
+    int cnt[HSUM_ROWS];
 #pragma unroll
-    for (int j = 0; j < 16; j++) cnt[j] = 0;
+    for (int j = 0; j < HSUM_ROWS; j++) cnt[j] = 0;
     double tot = 0.0;
-    fetch(0);
-    int b = 0;
-    for (int k0 = 0; k0 < nMax; k0 += 64, b ^= 1) {
+    auto consume = [&](double (&r)[HSUM_ROWS], int k0, int b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const bool in = regs[j] >= 0.0;
-            tile[b][lane][wave * 16 + j] = in ? regs[j] : -0.0;
+        for (int j = 0; j < HSUM_ROWS; j++) {
+            const bool in = r[j] >= 0.0;
+            tile[b][lane][j] = in ? r[j] : -0.0;
             cnt[j] += in ? 1 : 0;
         }
-        __syncthreads();
-        if (k0 + 64 < nMax) fetch(k0 + 64);
-        if (wave == 0) { // sixteen cells are on their way from LDS while the sixteen before them are added
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (k0 + DEPTH * 64 < nMax) fetch(r, k0 + DEPTH * 64);
+        if (lane < HSUM_ROWS) { // sixteen cells are on their way from LDS while the sixteen before them are added
             double v[16], w[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = tile[b][i][lane];
@@ -1959,16 +1961,24 @@ __global__ __launch_bounds__(256) void ransac_heavy_sum_kernel(const RansacArgs 
                 for (int i = 0; i < 16; i++) tot = tot + w[i];
             }
         }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d * 64 < nMax) fetch(regs[d], d * 64);
+    for (int k0 = 0; k0 < nMax; k0 += DEPTH * 64) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (k0 + d * 64 < nMax) consume(regs[d], k0 + d * 64, d & 1);
     }
 #pragma unroll
-    for (int j = 0; j < 16; j++) { // the wave's lanes hold 64 correspondences' worth of row wave * 16 + j
+    for (int j = 0; j < HSUM_ROWS; j++) { // the wave's lanes hold 64 correspondences' worth of row j each
         int c = cnt[j];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-        if (lane == 0) cnts[wave * 16 + j] = c;
+        if (lane == 0) cnts[j] = c;
     }
     __syncthreads();
-    if (wave == 0 && sP[lane] >= 0) {
+    if (lane < HSUM_ROWS && sP[lane] >= 0) {
         g.counts[(size_t)sP[lane] * g.H + sRow[lane]] = cnts[lane];
         g.toterr[(size_t)sP[lane] * g.H + sRow[lane]] = tot;
     }
@@ -3283,7 +3293,7 @@ static int ransac_run(sfm_ctx *ctx, int n_pairs, const int64_t *corr_offsets, co
                         hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_SAMPSON>, dim3(evalBlocks), dim3(256), 0, b->side, g);
                     else
                         hipLaunchKernelGGL(ransac_heavy_eval_kernel<SFM_LOSS_REPROJECTION>, dim3(evalBlocks), dim3(256), 0, b->side, g);
-                    hipLaunchKernelGGL(ransac_heavy_sum_kernel, dim3((unsigned)(g.heavyMax / 64)), dim3(256), 0, b->side, g);
+                    hipLaunchKernelGGL(ransac_heavy_sum_kernel, dim3((unsigned)(g.heavyMax / HSUM_ROWS)), dim3(64), 0, b->side, g);
                     SFM_HIP(ctx, hipEventRecord(b->sideDone, b->side));
                 }
                 hipLaunchKernelGGL(mk, mgrid, dim3(256), 0, st, g);
