@@ -109,6 +109,12 @@ const char *sfm_version(void);
  * is sampled, 64 x 256 cells, under the fp16 bound, and goes straight to the
  * filtered passes when that bound would overflow them as well, default; 0 =
  * it always tries the fp16 strict pass first; results are identical),
+ * "match_six_bit" (1 = image sets of batch calls also get a table of 6-bit
+ * floats (e2m3, 128 bytes per row), and the first bound pass of the cosine and
+ * L2 metrics runs on it, at twice the int8 rate of the matrix cores; its
+ * error bound is wider, and a pair it floods is redone under the int8 bound,
+ * default; 0 = the int8 pass comes first; set it before the image set is
+ * made; results are identical),
  * "match_dot_strict" (1 = with the dot metric a pair first takes the strict
  * passes under the cosine bound threshold / (largest norm of A x largest
  * norm of B), which is tight for descriptors of unit norm, default; 0 = the

@@ -25,6 +25,7 @@ struct sfm_ctx {
     int64_t pairs_per_launch = 2048; // image pairs per matcher chunk
     int match_two_phase = 1;         // 0: flagged pairs always take the filtered pass with running row bounds
     int match_flood_probe = 1;       // 0: pairs the int8 bound flooded always try the fp16 strict pass before the filtered ones
+    int match_six_bit = 1;           // 0: the first bound pass of the float matcher is the int8 one (no 6-bit table is made)
     int match_dot_strict = 1;        // 0: the dot metric scales the bound by the norms cell by cell for every pair
     int match_pair_reuse = 0;        // 1: the single-pair matcher takes image A from the device when it is the last call's image B (same host addresses and sizes: the caller promises the tables have not changed)
     int cand_observe = 1;            // calls of several chunks size the candidate lists of later chunks from the first one

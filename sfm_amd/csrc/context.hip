@@ -118,6 +118,8 @@ extern "C" int sfm_ctx_set_option(sfm_ctx *ctx, const char *key, int64_t value)
         ctx->match_two_phase = value != 0;
     } else if (!strcmp(key, "match_flood_probe")) {
         ctx->match_flood_probe = value != 0;
+    } else if (!strcmp(key, "match_six_bit")) {
+        ctx->match_six_bit = value != 0;
     } else if (!strcmp(key, "match_dot_strict")) {
         ctx->match_dot_strict = value != 0;
     } else if (!strcmp(key, "match_pair_reuse")) {

@@ -41,6 +41,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef int int8v __attribute__((ext_vector_type(8)));
 
 #define KDIM 128         // padded descriptor length of the fp16 table
 #define ROW_PAD 1024     // every image's fp16 rows are padded to a multiple of this
@@ -326,6 +327,82 @@ __global__ void ingest_i8_kernel(const float *__restrict__ desc32, const ImageRe
     *reinterpret_cast<int4v *>(desc8 + (size_t)(im.row16 + r) * 128 + k0) = out;
 }
 
+// The 6-bit table: e2m3 floats (sign, two exponent bits, three mantissa bits: 0, 1/8 ... 7/8, then 1 ... 7.5 in
+// steps of 1/8, 1/4 and 1/2), which the matrix cores multiply at twice the int8 rate.  One scale per image, a
+// power of two, puts the image's largest |element| into [3.75, 7.5].
+__host__ __device__ __forceinline__ float f6_scale(int largestBits)
+{
+    float mx;
+    memcpy(&mx, &largestBits, 4);
+    if (!(mx > 0.0f) || !(mx < 1e30f)) return 1.0f;
+    int e;
+    const float m = frexpf(mx, &e); // mx = m 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, m <= 0.9375f ? e - 3 : e - 2);
+}
+// x in [0, 7.5] to the nearest e2m3 value (ties to even, as rintf rounds).
+__device__ __forceinline__ float f6_round(float x)
+{
+    const float step = x < 2.0f ? 0.125f : (x < 4.0f ? 0.25f : 0.5f);
+    return fminf(rintf(x / step) * step, 7.5f);
+}
+__device__ __forceinline__ unsigned f6_bits(float v) // v: an e2m3 value (sign included)
+{
+    const unsigned sign = v < 0.0f ? 32u : 0u;
+    const float x = fabsf(v);
+    if (x < 1.0f) return sign | (unsigned)(x * 8.0f);
+    const int e = x < 2.0f ? 1 : (x < 4.0f ? 2 : 3);
+    return sign | ((unsigned)e << 3) | (unsigned)((x / (float)(1 << (e - 1)) - 1.0f) * 8.0f);
+}
+// One thread per 32 elements (a k-block of the 16x16x128 MFMA: 32 x 6 bits = six dwords per lane).  A row of 128 B
+// holds the first four dwords of its four k-blocks in its first 64 bytes and the last two of each, padded to 16
+// bytes, in its second: the 16-byte chunk a lane reads for k-block kb is chunk kb, then chunk 4 + kb -- the same
+// addresses as the two k-blocks of an int8 row, so the kernel stages and reads both tables alike.
+// err6[image] = the largest |a_hat - copy| over the image's rows (float bits, rounded up): what the bound on a
+// pair's approximation error is made of.
+__global__ __launch_bounds__(256) void ingest_f6_kernel(const float *__restrict__ desc32, const ImageRec *__restrict__ images,
+                                                        const float *__restrict__ norms, int dim, const int *__restrict__ stats,
+                                                        unsigned char *__restrict__ desc6, int *__restrict__ err6)
+{
+    const ImageRec im = images[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = t >> 2, kb = t & 3;
+    if ((blockIdx.x * blockDim.x) >> 2 >= im.n) return;
+    const bool valid = r < im.n;
+    float sq = 0.0f;
+    if (valid) {
+        const float s = norms[im.row32 + r];
+        const bool ok = (s >= 1e-12f) && (s <= 1e12f);
+        const float scale = f6_scale(stats[2 * blockIdx.y]);
+        const float *a = desc32 + (size_t)(im.row32 + r) * dim;
+        unsigned w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const int k = kb * 32 + j;
+            float v = 0.0f;
+            if (ok && k < dim) v = __fdiv_rn(a[k], s);
+            float q = f6_round(fminf(fabsf(v) / scale, 7.5f));
+            if (!(q == q)) q = 0.0f;
+            const float back = copysignf(q * scale, v);
+            const float d = back - v;
+            if (d == d) sq = fmaf(d, d, sq);
+            const unsigned bits = f6_bits(copysignf(q, v));
+            const int at = 6 * j;
+            w[at >> 5] |= bits << (at & 31);
+            if ((at & 31) > 26) w[(at >> 5) + 1] |= bits >> (32 - (at & 31));
+        }
+        unsigned char *row = desc6 + (size_t)(im.row16 + r) * 128;
+        *reinterpret_cast<uint4 *>(row + 16 * kb) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(row + 64 + 16 * kb) = make_uint4(w[4], w[5], 0u, 0u);
+    }
+    // the row's four threads are neighbours in the wave
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    // (the sum of 128 squares is good to a few 1e-6 of itself, the square root to one in 2^23: one part in a thousand covers both)
+    const float e = sqrtf(sq) * 1.001f + 1e-7f;
+    const int worst = wave_max(valid ? __float_as_int(e) : 0);
+    if ((threadIdx.x & 63) == 0 && worst > 0) atomicMax(&err6[blockIdx.y], worst);
+}
+
 // ---------------------------------------------------------------------------------------
 // per-pair candidate bounds
 // ---------------------------------------------------------------------------------------
@@ -342,6 +419,7 @@ struct BoundArgs {
     float ratio;
     float maxDistSq;
     int dotStrict; // dot metric: make a cosine bound for the strict passes (see below)
+    const int *err6; // [n] largest distance between a unit-normalised descriptor and its e2m3 copy (float bits), or null: no such table
 };
 __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ pairs, int nPairs, const BoundArgs b)
 {
@@ -410,8 +488,22 @@ __global__ __launch_bounds__(256) void pair_bounds_kernel(PairRec *__restrict__ 
         thr_i = -(1 << 30);
     else
         thr_i = (int)floor(t < 2.0e9 ? t : 2.0e9);
+    // Bound on the e2m3 dot product S6 = qa.qb with qa = (a_hat + e) / sA, qb = (b_hat + f) / sB, |e| <= EA, |f| <= EB:
+    // |a_hat.b_hat - S6 sA sB| = |e.b_hat + (a_hat + e).f| <= EA |b_hat| + (|a_hat| + EA) EB, with both norms below
+    // 1 + 1e-6.  The products of the MFMA are exact and its 128-term fp32 sum is good to 128 * 2^-23 of the sum of
+    // their magnitudes (at most (1 + EA)(1 + EB) in cosine units): 1e-4 covers that, and another 1e-4 the
+    // distance between a_hat.b_hat and the reference's cosine.
+    float thr6 = -INFINITY;
+    if (b.err6 && !(wild || (b.metric == SFM_METRIC_DOT && !dotStrict))) {
+        const double s6A = (double)f6_scale(b.stats[2 * ia]), s6B = (double)f6_scale(b.stats[2 * ib]);
+        const double EA = (double)__int_as_float(b.err6[ia]), EB = (double)__int_as_float(b.err6[ib]);
+        const double margin = EA * 1.000001 + (1.000001 + EA) * EB;
+        const double t6 = ((double)thrp - 2e-4 - margin * (1.0 + 1e-6)) / (s6A * s6B);
+        thr6 = (threshold != threshold) ? threshold : (float)(t6 - fabs(t6) * 1e-6); // (the conversion may round up)
+    }
     pairs[p].thr_m = thr_m;
     pairs[p].thr_i = thr_i;
+    pairs[p].thr6 = thr6;
     // Can the pixel gate (match.cpp:45) exclude any cell of this pair?  Not if the two images' points together
     // span less than the gate (the default, 10000^2, on any image below 7000 x 7000).
     bool gateOff = ((b.flags[ia] | b.flags[ib]) & IMG_PTS_WILD) == 0;
@@ -811,13 +903,15 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 {
     static_assert(MODE == 0 || (FORM == 0 && !DOT && !GENERAL), "the two-phase sweeps are fp16 strict instances");
     constexpr bool TWOSIDED = GENERAL || MODE != 0; // runs in both orientations, slices of both in the pair's list
-    // FORM 0: fp16 rows of 256 B; 1: int8 rows of 128 B; 2: int8 rows of 256 B (256 signs of a binary descriptor)
-    constexpr bool I8 = FORM != 0;       // int8 MFMA, int32 sums
-    constexpr bool WIDE = FORM != 1;     // 256-byte rows: the fp16 table's layout in memory and in LDS
+    // FORM 0: fp16 rows of 256 B; 1: int8 rows of 128 B; 2: int8 rows of 256 B (256 signs of a binary descriptor);
+    // 3: e2m3 rows of 128 B (one 16x16x128 MFMA per tile, fp32 sums)
+    constexpr bool I8 = FORM == 1 || FORM == 2; // int8 MFMA, int32 sums
+    constexpr bool F6 = FORM == 3;
+    constexpr bool WIDE = FORM == 0 || FORM == 2; // 256-byte rows: the fp16 table's layout in memory and in LDS
     constexpr int ROWB = WIDE ? 256 : 128;                   // bytes per descriptor row in the table and in LDS
     constexpr int DMA = SIM_BN * ROWB / 1024 / SIM_WAVES;  // LDS-DMA instructions per wave per step
     static_assert(SIM_BN * ROWB % (1024 * SIM_WAVES) == 0 && SIM_BN == 64, "step must split evenly");
-    static_assert(!I8 || (!GENERAL && !DOT), "the int8 bound has a strict cosine instance only");
+    static_assert(!(I8 || F6) || (!GENERAL && !DOT), "the int8 and e2m3 bounds have a strict cosine instance only");
     static_assert(GENERAL || !DOT, "the dot metric needs the general instance");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][SIM_BN * ROWB];
     // general instance: positions of the block's rows, of the staged columns, and the row bounds
@@ -852,13 +946,14 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rowBase = rowBlock * SIM_BLOCK_ROWS + wave * SIM_WAVE_ROWS;
 
-    const unsigned char *table = I8 ? reinterpret_cast<const unsigned char *>(g.desc8) : reinterpret_cast<const unsigned char *>(g.desc16);
+    const unsigned char *table = F6 ? g.desc6 : (I8 ? reinterpret_cast<const unsigned char *>(g.desc8) : reinterpret_cast<const unsigned char *>(g.desc16));
     const unsigned char *Arows = table + (size_t)(pr.rowA16 + rowBase) * ROWB;
     const unsigned char *Brows = table + (size_t)pr.rowB16 * ROWB;
 
-    // A fragments: row tile t (16 rows), k-block s; fp16 has four k-blocks of 32, int8 two of 64.
+    // A fragments: row tile t (16 rows), k-block s; fp16 has four k-blocks of 32, int8 two of 64; an e2m3 lane's 32
+    // elements of the tile's one k-block are the first 24 bytes of two such 16-byte pieces.
     constexpr int NKB = WIDE ? 4 : 2;
-    typedef typename std::conditional<I8, int4v, half8>::type Frag; // 16 bytes either way
+    typedef typename std::conditional<I8 || F6, int4v, half8>::type Frag; // 16 bytes either way
     Frag a[4][NKB];
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -874,6 +969,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     // the bound is the same for the whole block: keep it (and the branch on it) scalar
     const float thr_m = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pr.thr_m)));
     const int thr_i = __builtin_amdgcn_readfirstlane(pr.thr_i);
+    const float thr6 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pr.thr6)));
 
     // LDS-DMA: instruction u of this wave fills 1 KiB = four 256-B lines of the step; lane l lands
     // on line 4 (wave DMA + u) + (l >> 4), physical position l & 15, which holds the logical
@@ -910,6 +1006,12 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         }
     }
     using AccT = typename std::conditional<I8, SimAcc<int4v, int>, SimAcc<float4v, float>>::type;
+    // e2m3: the A operands, six dwords each (the block scale of both operands is 2^0: exponent byte 127)
+    int8v a6[F6 ? 4 : 1];
+    if constexpr (F6) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) a6[t] = int8v{a[t][0][0], a[t][0][1], a[t][0][2], a[t][0][3], a[t][1][0], a[t][1][1], 0, 0};
+    }
     // Two-phase sweeps: per lane its 16 rows (row tile t, register q: row 16 t + 4 (lane >> 4) + q of the wave).
     // MODE 1 keeps their running maxima; MODE 2 starts every accumulator at minus the row's bar.
     float rowVal[MODE != 0 ? 4 : 1][4];
@@ -942,26 +1044,44 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc.a[c][t][q] = fmaxf(rowVal[t][q], nb);
             }
-        } else {
+        } else if constexpr (!F6) {
             acc.zero();
         }
+        if constexpr (F6) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-            for (int s = 0; s < NKB; s++) {
+            for (int ct = 0; ct < 2; ct++) {
                 const int row = sub * 32 + ct * 16 + (lane & 15);
-                const int chunk = s * 4 + (lane >> 4);
-                const int at = !WIDE ? (row >> 1) * 256 + ((((row & 1) * 8 + chunk) ^ ((row >> 1) & 15)) << 4)
-                                  : row * 256 + ((chunk ^ (row & 15)) << 4);
-                const Frag b = *reinterpret_cast<const Frag *>(&lds[buf][at]);
+                Frag b[2];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if constexpr (I8)
-                        acc.a[ct][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][s], b, acc.a[ct][t], 0, 0, 0);
-                    else
-                        acc.a[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][s], b, acc.a[ct][t], 0, 0, 0);
+                for (int s = 0; s < 2; s++) {
+                    const int chunk = s * 4 + (lane >> 4);
+                    b[s] = *reinterpret_cast<const Frag *>(&lds[buf][(row >> 1) * 256 + ((((row & 1) * 8 + chunk) ^ ((row >> 1) & 15)) << 4)]);
                 }
+                const int8v b6 = {b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], 0, 0};
+                const float4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc.a[ct][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6[t], b6, zero, 2, 2, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
             }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                for (int s = 0; s < NKB; s++) {
+                    const int row = sub * 32 + ct * 16 + (lane & 15);
+                    const int chunk = s * 4 + (lane >> 4);
+                    const int at = !WIDE ? (row >> 1) * 256 + ((((row & 1) * 8 + chunk) ^ ((row >> 1) & 15)) << 4)
+                                      : row * 256 + ((chunk ^ (row & 15)) << 4);
+                    const Frag b = *reinterpret_cast<const Frag *>(&lds[buf][at]);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        if constexpr (I8)
+                            acc.a[ct][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][s], b, acc.a[ct][t], 0, 0, 0);
+                        else
+                            acc.a[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][s], b, acc.a[ct][t], 0, 0, 0);
+                    }
+                }
+        }
     };
     // this wave's slice of the pair's candidate list
     // (MODE 2: as many slices as the filtered passes would have, nQ0 + nQ1, shared out evenly among this sweep's
@@ -1003,7 +1123,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             }
         } else
             sim_epilogue<AccT, DOT, GENERAL, MODE == 2>(g, pr, acc, rowBase, colBase, lane,
-                                             typename AccT::VT(I8 ? thr_i : (MODE == 2 ? 0.0f : thr_m)), wq, localLo,
+                                             typename AccT::VT(I8 ? thr_i : (F6 ? thr6 : (MODE == 2 ? 0.0f : thr_m))), wq, localLo,
                                              GeneralLds{ptsRow + (GENERAL ? wave * SIM_WAVE_ROWS : 0),
                                                         &ptsCol[GENERAL ? buf : 0][GENERAL ? (colBase % SIM_BN) : 0],
                                                         rowBound + (GENERAL ? wave * SIM_WAVE_ROWS : 0)});
@@ -1082,7 +1202,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         if (wq.n > wq.cap) {
             // (the filtered passes rank cells by cosine, which is not the L2 order when norms differ: an L2 pair
             // whose fp16 strict list overflows is scored cell by cell)
-            const int flag = TWOSIDED ? 2 : (I8 ? 3 : (g.metric == SFM_METRIC_L2 ? 2 : 1));
+            const int flag = TWOSIDED ? 2 : (F6 ? 4 : (I8 ? 3 : (g.metric == SFM_METRIC_L2 ? 2 : 1)));
             g.pairOvf[pr.chunkLocal] = flag;
             atomicAdd(&g.flagCount[flag], 1); // "some pair carries this flag", for the passes that walk the list
         }
@@ -1218,6 +1338,8 @@ static void (*const kSimGeneral)(const MatchArgs) = match_sim_walk_kernel<2, fal
 static void (*const kSimRowMax)(const MatchArgs) = match_sim_walk_kernel<3, false, false, false, 0, 1>;
 static void (*const kSimBar)(const MatchArgs) = match_sim_walk_kernel<2, false, false, false, 0, 2>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
+static void (*const kSimSix)(const MatchArgs) = match_sim_kernel<5, 3, false, false, 0>;        // e2m3 bound, every pair
+static void (*const kSimEight)(const MatchArgs) = match_sim_walk_kernel<5, 1, false, false, 0>; // int8 bound, the pairs that one flooded
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
 // ---------------------------------------------------------------------------------------
@@ -1479,6 +1601,7 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
     if (s->owns_desc32) s->desc32.release();
     s->desc16.release();
     s->desc8.release();
+    s->desc6.release();
     s->desc8u.release();
     s->imageStats.release();
     s->norms.release();
@@ -1493,7 +1616,7 @@ extern "C" void sfm_imageset_destroy(sfm_imageset *s)
 extern "C" int64_t sfm_imageset_device_bytes(const sfm_imageset *s)
 {
     if (!s) return 0;
-    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->desc8u.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageStats.cap);
+    return (int64_t)(s->desc32.cap + s->desc16.cap + s->desc8.cap + s->desc6.cap + s->desc8u.cap + s->norms.cap + s->pts.cap + s->imageRecs.cap + s->imageStats.cap);
 }
 
 // Two host tables that together form the set's table (image 0 then image 1): the single-pair entry
@@ -1639,14 +1762,18 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
     SET_HIP(s->desc16.reserve((size_t)r16 * KDIM * sizeof(_Float16)));
     SET_HIP(s->desc8.reserve((size_t)r16 * 128));
     const size_t nImg = (size_t)(n_images ? n_images : 1);
-    SET_HIP(s->imageStats.reserve(nImg * 9 * sizeof(int))); // [n][2] int8 statistics, [n][2] norm range, [n] flags, [n][4] extent of the points
+    // The 6-bit table serves the first bound pass of batch calls; a set made for one single-pair call goes without.
+    const bool six = ctx->match_six_bit && !no_wait;
+    if (six) SET_HIP(s->desc6.reserve((size_t)r16 * 128));
+    SET_HIP(s->imageStats.reserve(nImg * 10 * sizeof(int))); // [n][2] int8 statistics, [n][2] norm range, [n] flags, [n][4] extent of the points, [n] e2m3 error
     SET_HIP(s->norms2.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(s->norms.reserve((size_t)(r32 ? r32 : 1) * sizeof(float)));
     SET_HIP(s->imageRecs.reserve(nImg * sizeof(ImageRec)));
     // the padding rows of both tables must read as zero, and the per-image words start at zero
     SET_HIP(clear_ranges(ctx->stream, {{s->desc8.p, (size_t)r16 * 128},
                                        {s->desc16.p, (size_t)r16 * KDIM * sizeof(_Float16)},
-                                       {s->imageStats.p, nImg * 9 * sizeof(int)}}));
+                                       {s->imageStats.p, nImg * 10 * sizeof(int)},
+                                       {six ? s->desc6.p : nullptr, six ? (size_t)r16 * 128 : 0}}));
     int *const imageFlags = s->imageStats.as<int>() + 4 * nImg;
     s->flags.assign(n_images, 0);
     if (n_images > 0 && maxN > 0) {
@@ -1663,6 +1790,12 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
         hipLaunchKernelGGL(ingest_i8_kernel, g3, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
                            s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>(),
                            s->desc8.as<signed char>());
+        if (six) {
+            dim3 g6(((int64_t)maxN * 4 + 255) / 256, n_images);
+            hipLaunchKernelGGL(ingest_f6_kernel, g6, dim3(256), 0, ctx->stream, s->desc32.as<float>(),
+                               s->imageRecs.as<ImageRec>(), s->norms.as<float>(), dim, s->imageStats.as<int>(),
+                               s->desc6.as<unsigned char>(), s->imageStats.as<int>() + 9 * nImg);
+        }
         SET_HIP(hipGetLastError());
         if (!no_wait) { // the flags decide below whether the exact pass gets a byte copy
             SET_HIP(hipMemcpyAsync(s->flags.data(), imageFlags, (size_t)n_images * sizeof(int),
@@ -1810,11 +1943,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         } else {
             res->candObserved = 0;
             res->floodObserved = false;
+            res->sixFlooded = false;
             probing = true;
         }
     } else {
         res->candObserved = 0;
         res->floodObserved = false;
+        res->sixFlooded = false;
     }
     memset(&res->observedFor, 0, sizeof res->observedFor);
     res->observedFor = key;
@@ -2001,7 +2136,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         SFM_HIP(ctx, reserve_lists());
     const size_t candCountSet = (size_t)round_up((int64_t)((size_t)chunkPairs * maxQueues * sizeof(int)), 256);
     SFM_HIP(ctx, res->candCount.reserve(candCountSet * sets));
-    const size_t pairOvfSet = (size_t)round_up((int64_t)((size_t)(chunkPairs + 4) * sizeof(int)), 256); // flags, then how often each value was set
+    const size_t pairOvfSet = (size_t)round_up((int64_t)((size_t)(chunkPairs + FLAG_VALUES) * sizeof(int)), 256); // flags, then how often each value was set
     SFM_HIP(ctx, res->pairOvf.reserve(pairOvfSet * sets));
     const size_t bestSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(u64)), 256);
     SFM_HIP(ctx, res->best.reserve(bestSet * sets));
@@ -2051,6 +2186,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     g.flagOut = packed ? reinterpret_cast<int *>(packed + 8) : nullptr;
     g.desc16 = set->desc16.as<_Float16>();
     g.desc8 = set->desc8.as<signed char>();
+    g.desc6 = set->desc6.p ? set->desc6.as<unsigned char>() : nullptr;
     g.desc8u = set->u8_exact ? set->desc8u.as<unsigned char>() : nullptr;
     g.desc32 = set->desc32.as<float>();
     g.norms = set->norms.as<float>();
@@ -2082,11 +2218,14 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         bool gaveUp = false; // a pair went to the cell-by-cell pass: the maximum was not enough for it
         for (size_t k = 0; k < nCount; k++) fullest = std::max(fullest, seen[k]);
         int flooded = 0; // pairs whose int8 lists overflowed and that the fp16 strict pass did not settle either
+        int flagged = 0; // pairs that any strict pass gave up on (the first of them is the e2m3 pass when there is one)
         for (int k = 0; k < np; k++) {
             gaveUp = gaveUp || seen[nCount + k] == 2;
             flooded += (seen[nCount + k] == 1 || seen[nCount + k] == 2) ? 1 : 0;
+            flagged += seen[nCount + k] != 0 ? 1 : 0;
         }
         res->floodObserved = np >= 16 && 10 * flooded >= 9 * np;
+        res->sixFlooded = 2 * flagged >= np;
         int64_t slice = 64;
         while (slice < 2 * (int64_t)fullest + 64) slice *= 2;
         candCap = gaveUp ? candCapMax : (int)std::min<int64_t>(candCapMax, slice * maxQueues);
@@ -2107,7 +2246,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             SFM_HIP(ctx, hipMemcpyAsync(res->work.as<int2>() + w0, work + w0, (size_t)wn * sizeof(int2), hipMemcpyHostToDevice, up));
         const int nImg = set->n_images ? set->n_images : 1;
         const BoundArgs b = {set->imageStats.as<int>(), set->imageStats.as<int>() + 4 * (size_t)nImg, set->imageStats.as<unsigned>() + 5 * (size_t)nImg,
-                             nImg, set->dim, metric, threshold, ratio, maxDistSq, dotStrict ? 1 : 0};
+                             nImg, set->dim, metric, threshold, ratio, maxDistSq, dotStrict ? 1 : 0,
+                             set->desc6.p ? set->imageStats.as<int>() + 9 * (size_t)nImg : nullptr};
         hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, up, res->pairRecs.as<PairRec>() + c0, np, b);
         if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[7 + (int)(ci % (size_t)sets)], up));
         return SFM_OK;
@@ -2150,7 +2290,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         } else { // (the first chunk also clears the first offset and the call's counters)
             SFM_HIP(ctx, clear_ranges(st, {{bestBuf, (size_t)bestLen * sizeof(u64)},
                                            {candCountBuf, (size_t)np * maxQueues * sizeof(int)},
-                                           {pairOvfBuf, (size_t)(chunkPairs + 4) * sizeof(int)},
+                                           {pairOvfBuf, (size_t)(chunkPairs + FLAG_VALUES) * sizeof(int)},
                                            {res->offsets.p, ci == 0 ? sizeof(int64_t) : 0},
                                            {res->stats.p, ci == 0 ? 4 * sizeof(u64) : 0}}));
         }
@@ -2175,11 +2315,16 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             const bool guessable = variant.strict16 && ctx->match_flood_probe && metric == SFM_METRIC_COSINE && ratio == 0.0f;
             const int pairGuess = (want_m1m2 && guessable && pairGuessFrom && twoPhase) ? (pairGuessFrom == 3 ? 3 : 1) : 0;
             const bool skipInt8 = pairGuess != 0 || (res->floodObserved && !probe && guessable);
+            // The e2m3 bound comes first where there is a table for it: twice the int8 rate, a wider margin.  The
+            // pairs it floods are redone under the int8 bound; when half the observed first chunk was, the later
+            // chunks start with int8 as if there were no such table.  (Single-pair calls have none.)
+            const bool sixFirst = strictFirst && !skipInt8 && g.desc6 && ctx->sim_variant == 1 && (probe || !res->sixFlooded);
             if (strictFirst) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
                 if (skipInt8)
                     hipLaunchKernelGGL(match_flag_flooded_kernel, dim3((np + 255) / 256), dim3(256), 0, st, g, np, pairGuess ? pairGuess : 3);
+                else if (sixFirst) hipLaunchKernelGGL(kSimSix, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
                 else hipLaunchKernelGGL(variant.strict, dim3(nblk), dim3(SIM_WAVES * 64), 0, st, g);
                 SFM_HIP(ctx, sfm_span_end(ctx, 0, st));
                 // The first bound passes of consecutive chunks follow each other on this stream (each fills the
@@ -2196,6 +2341,11 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             if (ci + 1 < (size_t)nChunks) { // while the device runs this chunk, the host prepares the next
                 const int rc = upload(ci + 1);
                 if (rc != SFM_OK) return rc;
+            }
+            if (sixFirst) { // pairs flooded under the e2m3 margin: int8 bound
+                g.onlyFlagged = 4;
+                g.nWork = nblk;
+                hipLaunchKernelGGL(kSimEight, dim3(std::min(nblk, walk_grid(5))), dim3(SIM_WAVES * 64), 0, st, g);
             }
             if (strictFirst && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 if (ctx->match_flood_probe && metric == SFM_METRIC_COSINE && pairGuess != 1)
@@ -2339,7 +2489,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         if (overlap && ci + sets < (size_t)nChunks) { // clear the set for the chunk that takes it next (sizes: upper bounds)
             if (maxBest > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)maxBest * sizeof(u64), st));
             SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)chunkPairs * maxQueues * sizeof(int), st));
-            SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + 4) * sizeof(int), st));
+            SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + FLAG_VALUES) * sizeof(int), st));
             SFM_HIP(ctx, hipEventRecord(ctx->ev[3 + par], st));
         }
         SFM_HIP(ctx, hipGetLastError());

@@ -11,10 +11,13 @@ struct PairRec {
     int64_t bestRow, bestCol; // first slot in the best[] array of the chunk
     float thr_m;            // candidate bound on the approximate cosine
     int32_t thr_i;          // the same bound on the int8 dot product (instances that use the int8 table)
+    float thr6;             // the same bound on the e2m3 dot product (instances that use the 6-bit table)
     int32_t chunkLocal;     // index inside the chunk
     int32_t ia, ib;         // the two images in their set (float matcher: the bounds are made from their statistics on the device)
     int32_t gateOff;        // 1: the pixel gate cannot exclude any cell of this pair (made on the device with the bounds)
 };
+
+#define FLAG_VALUES 5 // values a pair's overflow flag takes, 0 included
 
 struct ImageRec {
     int32_t n;
@@ -28,6 +31,7 @@ typedef unsigned long long u64;
 struct MatchArgs {
     const _Float16 *desc16;
     const signed char *desc8; // unit-normalised descriptors quantised to int8, 128 bytes per row
+    const unsigned char *desc6; // unit-normalised descriptors as e2m3 (6-bit floats), 128 bytes per row (see ingest_f6_kernel), or null
     const unsigned char *desc8u; // byte copy of desc32 (dim 128, rows as desc32) when every element is an integer in [0, 255], else null
     const float *desc32;
     const float *norms;
@@ -37,8 +41,8 @@ struct MatchArgs {
     const int2 *work;     // (pair in chunk, row block), -1 = no work
     uint2 *cand;          // [pairs in chunk][candCap]
     int *candCount;       // [pairs in chunk][maxQueues]: entries in each wave's slice
-    int *pairOvf;         // [pairs in chunk]: a slice overflowed in 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
-    int *flagCount;       // [4]: how often a flag value was set in this chunk (only zero / non-zero matters)
+    int *pairOvf;         // [pairs in chunk]: a slice overflowed in 4 = the e2m3 strict pass, 3 = the int8 strict pass, 1 = the fp16 strict pass, 2 = the general pass
+    int *flagCount;       // [FLAG_VALUES]: how often a flag value was set in this chunk (only zero / non-zero matters)
     int *flagOut;         // single-pair calls: where the pair's final flag goes (beside the packed count), or null
     int onlyFlagged;      // != 0: this pass handles only the pairs whose flag has this value
     int nWork;            // entries of the work list (passes that walk it)
@@ -73,11 +77,12 @@ struct sfm_imageset {
     std::vector<ImageRec> images;
     std::vector<int> flags;
     int64_t rows32 = 0, rows16 = 0;
-    DevBuf desc32, desc16, desc8, desc8u, norms, norms2, pts, imageRecs, imageStats;
+    DevBuf desc32, desc16, desc8, desc6, desc8u, norms, norms2, pts, imageRecs, imageStats;
     // imageStats (device, ints holding float bit patterns): [image][2] = largest |element| and largest L1 norm of the
     // unit-normalised descriptors (the int8 value of an element is round(element * 127 / largest)), then
     // [image][2] = 0x7FFFFFFF - bits of the smallest norm, bits of the largest (norms inside the safe range),
-    // then [image] = IMG_* flags.
+    // then [image] = IMG_* flags, [image][4] = the extent of the points, and [image] = the largest distance between a
+    // unit-normalised descriptor and its e2m3 copy (float bits, rounded up).
     bool owns_desc32 = true, owns_pts = true;
     bool flags_on_host = true; // false: built without waiting for the device (single-pair calls); flags stays zero
     bool u8_exact = false;     // desc8u holds a byte copy of desc32 (every element an integer in [0, 255], dim 128)
@@ -102,6 +107,7 @@ struct sfm_match_result {
     DevBuf rowMax;           // two-phase filtered passes: a float per row of a chunk (per buffer set)
     DevBuf candProbe;        // lists of the first chunk of a call that observes how far they fill
     int candObserved = 0;    // candidate slots per pair sized from such a first chunk (0 = none yet)
+    bool sixFlooded = false;    // in that first chunk half the pairs or more flooded their e2m3 lists: later chunks start with int8
     bool floodObserved = false; // in that first chunk nine pairs in ten flooded their int8 lists and went on to the filtered passes
     MatchKey observedFor = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};
     size_t packedBytes = 0; // single-pair calls: bytes of m1 before the list (count, per-row and per-column bests)
