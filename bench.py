@@ -36,7 +36,10 @@ if ROOT not in sys.path:
 
 PEAK_F16_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak of MI355X
 PEAK_I8_TOPS = 5000.0      # dense int8 MFMA peak: the 16x16x64 int8 form takes the cycles of the bf16 16x16x32 form at twice the K
-BOUNDS = {"int8": (1, "i8", PEAK_I8_TOPS), "fp16": (0, "f16", PEAK_F16_TFLOPS)}  # sim_variant, dtype, peak
+PEAK_F6_TFLOPS = 10000.0   # dense 6-bit / 4-bit MFMA peak: the 16x16x128 form with e2m3 operands takes those cycles at four times the K
+# sim_variant, match_six_bit, dtype, peak: what the first bound pass of every pair computes in
+BOUNDS = {"e2m3": (1, 1, "f6 (e2m3)", PEAK_F6_TFLOPS), "int8": (1, 0, "i8", PEAK_I8_TOPS), "fp16": (0, 0, "f16", PEAK_F16_TFLOPS)}
+DTYPE_NOTES = {"e2m3": "e2m3-in/fp32-acc", "int8": "int8-in/int32-acc", "fp16": "fp16-in/fp32-acc"}
 RANSAC_BYTES_PER_PAIR = 1_082_368  # 20 000 corr * 32 B + 4096 hyp * (96 + 12) B
 # Vector-ALU issue peak: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles each, at the 2.4 GHz behind the
 # data sheet's vector figures (157.3 TFLOP/s fp32 = 1024 SIMDs x 16 lanes x 2 (packed) x 2 (fma) x 2.4 GHz).
@@ -68,7 +71,7 @@ def main():
     ap.add_argument("--no-regimes", action="store_true", help="skip the matcher's other regimes and the extra RANSAC rows")
     ap.add_argument("--ransac-corr", type=int, default=20000)
     ap.add_argument("--ransac-hyps", type=int, default=4096)
-    ap.add_argument("--bound", choices=sorted(BOUNDS), default="int8",
+    ap.add_argument("--bound", choices=sorted(BOUNDS), default="e2m3",
                     help="arithmetic of the matcher's similarity bound (the exact re-scoring is fp32 either way)")
     ap.add_argument("--first-slice", type=int, default=0,
                     help="rows of the first slice of adaptive RANSAC batches (0 = the library's default)")
@@ -106,10 +109,11 @@ def main():
                 os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     ctx = capi.Context(local_rank)
-    sim_variant, bound_dtype, bound_peak = BOUNDS[args.bound]
+    sim_variant, six_bit, bound_dtype, bound_peak = BOUNDS[args.bound]
     if "SFM_SIM_VARIANT" in os.environ:  # the library's timing-only ablations of the similarity kernel (wrong results)
         sim_variant = int(os.environ["SFM_SIM_VARIANT"])
     ctx.set_option("sim_variant", sim_variant)
+    ctx.set_option("match_six_bit", six_bit)
     if "SFM_MATCH_OVERLAP" in os.environ:  # A/B switch of the matcher's two-stream chunk overlap
         ctx.set_option("match_overlap", int(os.environ["SFM_MATCH_OVERLAP"]))
     if "SFM_MATCH_LIST_OBSERVE" in os.environ:  # A/B switch: match lists sized as the call goes / for the worst case
@@ -268,7 +272,7 @@ def main():
         "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": bound_dtype,
-        "dtype_note": ("int8-in/int32-acc" if args.bound == "int8" else "fp16-in/fp32-acc") +
+        "dtype_note": DTYPE_NOTES[args.bound] +
                       " MFMA bounds every cell; cells that can pass are re-scored in the "
                       "reference's fp32 operation order, so match lists are bit-exact",
         "data": "synthetic",
@@ -289,12 +293,13 @@ def main():
         "roofline": {
             "bound": "mfma", "kernel": "match_sim_kernel",
             "achieved": round(achieved_tflops, 2), "peak": bound_peak, "unit": "TFLOP/s",
-            "unit_note": "algorithmic 2*N*M*D operations per pair; with the int8 bound they are integer multiply-adds",
+            "unit_note": "algorithmic 2*N*M*D operations per pair, priced against the dense matrix-core peak of the bound's operand type "
+                         "(e2m3 10 000, int8 5 000, fp16 2 500 TFLOP/s)",
             "frac": round(achieved_tflops / bound_peak, 4),
             "traffic": measured_traffic(len(my_pairs) * args.steps / max(kernel_launches, 1), args.bound),
             "traffic_unit": "HBM bytes per launch",
             "traffic_source": "static, not measured in this run: bytes per pair from the committed rocprofv3 PMC passes "
-                              "(profiles/r3_pmc_traffic_i8.json, r1_pmc_traffic.json for the fp16 bound: separate FETCH_SIZE / WRITE_SIZE "
+                              "(profiles/r3_pmc_traffic_f6.json; r3_pmc_traffic_i8.json and r1_pmc_traffic.json for the int8 and fp16 bounds: separate FETCH_SIZE / WRITE_SIZE "
                               "runs of this script, scripts/pmc_traffic.sh) "
                               "times this run's pairs per launch",
             "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4), "launches": kernel_launches,
@@ -380,11 +385,11 @@ def check_gather(torch, dist, ctx, comm, gathered, imgset, pair_list, total_pair
     return {"sum_of_rank_totals": want, "sampled_pairs_equal_to_single_gpu_lists": int(len(sample))}
 
 
-def measured_traffic(pairs_per_launch, bound="int8"):
+def measured_traffic(pairs_per_launch, bound="e2m3"):
     """HBM bytes per launch of the similarity kernel from the committed PMC pass (FETCH_SIZE and
     WRITE_SIZE are collected by rocprofv3 in separate runs of this script, not inline), scaled to
     this run's pairs per launch; None if the profile is absent."""
-    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic_i8.json" if bound == "int8" else "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", {"e2m3": "r3_pmc_traffic_f6.json", "int8": "r3_pmc_traffic_i8.json"}.get(bound, "r1_pmc_traffic.json"))
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -394,7 +399,7 @@ def measured_traffic(pairs_per_launch, bound="int8"):
 
 def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     """The matcher outside the headline's best case.  The headline's descriptors let the int8 bound admit
-    nothing but true matches; these rows show what the same entry point costs when it does not:
+    nothing but true matches (nor does the e2m3 bound that now comes first); these rows show what the same entry point costs when it does not:
     the fp16 bound on the same data, the reference's default threshold (match.hpp:59: 0.5, where most cells
     pass and the row-best / column-best filter decides), Gaussian float descriptors, and a distribution whose
     unrelated descriptors sit at cosine 0.93, inside the int8 margin of a 0.95 threshold (every pair is redone
@@ -404,14 +409,16 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     n = args.features
 
     def row(label, s, pl, thr, variant, note, metric=0):
-        sv, dtype, peak = BOUNDS[variant]
+        sv, six, dtype, peak = BOUNDS[variant]
         ctx.set_option("sim_variant", sv)
+        ctx.set_option("match_six_bit", six)
         res = s.match(pl, threshold=thr, max_dist_sq=1e8, metric=metric)
         ctx.synchronize()
         t0 = time.perf_counter()
         res = s.match(pl, threshold=thr, max_dist_sq=1e8, result=res, metric=metric)
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        ctx.set_option("match_six_bit", 1)  # (image sets made between the rows get the 6-bit table)
         ms, launches = ctx.last_kernel_ms(0)
         cand, cells, filtered, redone = res.stats_ex()
         out = {"workload": label, "threshold": thr, "bound": variant, "pairs": len(pl), "pairs_per_s": round(len(pl) / dt, 1),
@@ -432,18 +439,20 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
 
     rows = []
     head = np.ascontiguousarray(pair_list[:min(len(pair_list), 4096)])
+    rows.append(row("the headline's images", imgset, head, args.threshold, "int8",
+                    "int8 bound as the first pass instead of e2m3: half the MFMA rate, a margin of 2-4e-2 instead of 0.1"))
     rows.append(row("the headline's images", imgset, head, args.threshold, "fp16",
-                    "fp16 bound instead of int8: half the MFMA rate, a margin of 1.5e-3 instead of 2-4e-2"))
+                    "fp16 bound as the first pass: a quarter of the e2m3 rate, a margin of 1.5e-3"))
     loose = np.ascontiguousarray(pair_list[:min(len(pair_list), 1024)])
-    rows.append(row("the headline's images", imgset, loose, 0.5, "int8",
+    rows.append(row("the headline's images", imgset, loose, 0.5, "e2m3",
                     "the reference's default threshold: nearly every cell passes, the strict lists overflow, one sweep finds the maxima of rows and columns and one collects the cells within reach of them"))
     n_img = 40
     pl = synth.exhaustive_pairs(n_img)
     d, p, c = synth.image_set(n_img, n, seed=2027, kind="gauss")
     s = ctx.imageset(c, d, p)
     rows.append(row(f"{n_img} images x {n} Gaussian float descriptors (sigma 1; shared features re-detected with noise 0.05)",
-                    s, pl, args.threshold, "int8", "general floats: exact pass reads the fp32 table"))
-    rows.append(row(f"{n_img} images x {n} Gaussian float descriptors", s, pl, 0.5, "int8",
+                    s, pl, args.threshold, "e2m3", "general floats: exact pass reads the fp32 table"))
+    rows.append(row(f"{n_img} images x {n} Gaussian float descriptors", s, pl, 0.5, "e2m3",
                     "unrelated Gaussian descriptors have cosine ~ N(0, 1/128): 0.5 is still selective"))
     s.close()
     # the reference's other metric on descriptors of unit norm, where it equals the cosine up to rounding
@@ -452,7 +461,7 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     s = ctx.imageset(c, unit, p)
     pl24 = synth.exhaustive_pairs(24)
     rows.append(row_metric("24 of the headline's images, rows scaled to unit norm, dotProduct (match.hpp:18-27)", s, pl24, args.threshold,
-                           "int8", capi.METRIC_DOT, "a.b > T implies a cosine above T / (maxA maxB): strict passes under that bound, "
+                           "e2m3", capi.METRIC_DOT, "a.b > T implies a cosine above T / (maxA maxB): strict passes under that bound, "
                                                     "the exact pass scores the dot product"))
     s.close()
     rng = np.random.default_rng(7)
@@ -464,8 +473,8 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     pts = rng.uniform(0, 4000, (n_img * n, 2))
     s = ctx.imageset(np.full(n_img, n, np.int32), hard, pts)
     rows.append(row(f"{n_img} images x {n} SIFT-like descriptors with a common part: unrelated cosines ~0.93", s,
-                    pl, args.threshold, "int8",
-                    "the int8 margin admits the unrelated cells, lists flood, the fp16 bound redoes every pair"))
+                    pl, args.threshold, "e2m3",
+                    "the e2m3 and int8 margins admit the unrelated cells, lists flood, the fp16 bound redoes every pair"))
     s.close()
     return rows
 

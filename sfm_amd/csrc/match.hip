@@ -640,6 +640,9 @@ __device__ __forceinline__ int opaque_zero()
 // Operand map of both: lane l holds A[row l & 15][k-group l >> 4] and B[k-group l >> 4][col l & 15]
 // (8 halves or 16 bytes per group); result register q of lane l is C[4 (l >> 4) + q][l & 15].
 #define SIM_WAVES 4
+#ifndef SIX_OCC
+#define SIX_OCC 5 // blocks per CU the e2m3 instance is compiled for
+#endif
 #define SIM_WAVE_ROWS 64
 #define SIM_BLOCK_ROWS (SIM_WAVES * SIM_WAVE_ROWS)
 #define SIM_BN 64
@@ -726,30 +729,38 @@ struct GeneralLds {
 // shared bound, which keeps the test permissive.
 // SWAP (strict instances that run with either image in the register-resident role): rows are image B's when
 // g.orient is set, and the pairs go out as (row of A, row of B) all the same.
+// Strict instances: four independent chains of maxima over a lane's 32 accumulators (chain k takes accumulators
+// 8 m + 2 k and 8 m + 2 k + 1) keep the dependent-issue latency short; no branch, so the chains can be scheduled
+// among MFMAs.  fmaxf ignores NaNs, and a NaN cell can never be accepted.
+template <typename AccT> __device__ __forceinline__ void strict_maxima(const AccT &acc, typename AccT::VT (&m)[4])
+{
+    constexpr bool INTEGER = std::is_same<typename AccT::VT, int>::value;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if constexpr (INTEGER) m[k] = INT_MIN;
+        else m[k] = -INFINITY;
+    }
+#pragma unroll
+    for (int idx = 0; idx < AccT::NV; idx += 2) {
+        if constexpr (INTEGER) m[(idx >> 1) & 3] = max(max(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
+        else m[(idx >> 1) & 3] = fmaxf(fmaxf(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
+    }
+}
+
+// m: the strict instances' chain maxima of acc (strict_maxima; the general instance does not look at them).
 template <typename AccT, bool DOT, bool GENERAL, bool SWAP = false>
 __device__ __forceinline__ void sim_epilogue(const MatchArgs &g, const PairRec &pr, const AccT &acc, int rowBase,
                                              int colBase, int lane, typename AccT::VT thr_m, WaveQueue &wq,
-                                             float (&localLo)[GENERAL ? AccT::NV : 1], const GeneralLds &gl)
+                                             float (&localLo)[GENERAL ? AccT::NV : 1], const GeneralLds &gl,
+                                             const typename AccT::VT (&m)[4])
 {
     constexpr int NV = AccT::NV;
     constexpr bool INTEGER = std::is_same<typename AccT::VT, int>::value;
     static_assert(!INTEGER || !GENERAL, "the int8 bound has a strict instance only");
     unsigned bits = 0;
-    // Strict instances: four independent chains of maxima (chain k takes accumulators 8 m + 2 k and 8 m + 2 k + 1)
-    // keep the dependent-issue latency short; no branch, so the chains can be scheduled among MFMAs.  fmaxf
-    // ignores NaNs, and a NaN cell can never be accepted.
-    typename AccT::VT m[4];
     if constexpr (INTEGER) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) m[k] = INT_MIN;
-#pragma unroll
-        for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = max(max(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
         bits = max(max(m[0], m[1]), max(m[2], m[3])) > thr_m;
     } else if constexpr (!GENERAL) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) m[k] = -INFINITY;
-#pragma unroll
-        for (int idx = 0; idx < NV; idx += 2) m[(idx >> 1) & 3] = fmaxf(fmaxf(m[(idx >> 1) & 3], acc.get(idx)), acc.get(idx + 1));
         bits = fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])) > thr_m;
     } else if (DOT) {
         bits = 0xFFFFFFFFu;
@@ -1121,12 +1132,15 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
                     for (int q = 0; q < 4; q += 2) cm = fmaxf(fmaxf(cm, acc.a[ct][t][q]), acc.a[ct][t][q + 1]);
                 atomicMax(&colMaxL[buf][(colBase & (SIM_BN - 1)) + ct * 16 + (lane & 15)], __float_as_uint(cm));
             }
-        } else
+        } else {
+            typename AccT::VT m[4] = {};
+            if constexpr (!GENERAL) strict_maxima(acc, m);
             sim_epilogue<AccT, DOT, GENERAL, MODE == 2>(g, pr, acc, rowBase, colBase, lane,
                                              typename AccT::VT(I8 ? thr_i : (F6 ? thr6 : (MODE == 2 ? 0.0f : thr_m))), wq, localLo,
                                              GeneralLds{ptsRow + (GENERAL ? wave * SIM_WAVE_ROWS : 0),
                                                         &ptsCol[GENERAL ? buf : 0][GENERAL ? (colBase % SIM_BN) : 0],
-                                                        rowBound + (GENERAL ? wave * SIM_WAVE_ROWS : 0)});
+                                                        rowBound + (GENERAL ? wave * SIM_WAVE_ROWS : 0)}, m);
+        }
     };
 
     AccT acc;
@@ -1326,6 +1340,9 @@ static const SimVariant kSimVariants[] = {
     {match_sim_kernel<5, true, false, false, 3>, nullptr, "int8, neither staging nor test (timing only)"},      // 5
     {match_sim_kernel<5, true, false, false, 4>, nullptr, "int8, candidates not stored (timing only)"},         // 6
     {match_sim_kernel<5, true, false, false, 8>, nullptr, "int8, hits not queued (timing only)"},               // 7
+    {match_sim_kernel<5, 3, false, false, 2>, nullptr, "e2m3, no candidate test (timing only)"},                // 8
+    {match_sim_kernel<5, 3, false, false, 3>, nullptr, "e2m3, neither staging nor test (timing only)"},         // 9
+    {match_sim_kernel<5, 3, false, false, 8>, nullptr, "e2m3, hits not queued (timing only)"},                  // 10
 };
 // cosine with the row-best filter (loose thresholds), and the dot metric: fp16 bound, two blocks per CU
 // Binary descriptors as 256 signs (+1 / -1) per row: the int32 sum is 256 - 2 * Hamming distance, exactly.
@@ -1338,7 +1355,7 @@ static void (*const kSimGeneral)(const MatchArgs) = match_sim_walk_kernel<2, fal
 static void (*const kSimRowMax)(const MatchArgs) = match_sim_walk_kernel<3, false, false, false, 0, 1>;
 static void (*const kSimBar)(const MatchArgs) = match_sim_walk_kernel<2, false, false, false, 0, 2>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
-static void (*const kSimSix)(const MatchArgs) = match_sim_kernel<5, 3, false, false, 0>;        // e2m3 bound, every pair
+static void (*const kSimSix)(const MatchArgs) = match_sim_kernel<SIX_OCC, 3, false, false, 0>;        // e2m3 bound, every pair
 static void (*const kSimEight)(const MatchArgs) = match_sim_walk_kernel<5, 1, false, false, 0>; // int8 bound, the pairs that one flooded
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
@@ -2318,7 +2335,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             // The e2m3 bound comes first where there is a table for it: twice the int8 rate, a wider margin.  The
             // pairs it floods are redone under the int8 bound; when half the observed first chunk was, the later
             // chunks start with int8 as if there were no such table.  (Single-pair calls have none.)
-            const bool sixFirst = strictFirst && !skipInt8 && g.desc6 && ctx->sim_variant == 1 && (probe || !res->sixFlooded);
+            const bool sixFirst = strictFirst && !skipInt8 && g.desc6 && ctx->match_six_bit && ctx->sim_variant == 1 && (probe || !res->sixFlooded);
             if (strictFirst) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;

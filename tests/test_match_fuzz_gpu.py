@@ -63,12 +63,21 @@ def test_random_batch(ctx, oracle, seed):
     counts = rng.choice([0, 1, 40, 256, 257, 600, 1100], n_img).astype(np.int32)
     n = max(int(counts.max()), 1)
     d, p, _ = synth.image_set(n_img, n, shared_frac=float(rng.uniform(0.1, 0.7)), seed=int(rng.integers(1 << 30)))
+    kind = str(rng.choice(["sift", "sift", "common part", "gauss"]))
+    if kind == "common part":  # unrelated cosines near the threshold: inside the margin of the 6-bit bound, of the int8 bound, or of neither
+        base = synth.sift_like(rng, 1)[0]
+        keep = rng.random(len(d)) < 0.3  # (rows kept from the usual set still match across images)
+        mixed = np.floor(np.clip(base[None, :] * 0.9 + synth.sift_like(rng, len(d)) * float(rng.choice([0.42, 0.6, 0.8])), 0, 255)).astype(np.float32)  # (whole numbers: the table may go up as bytes)
+        d = np.where(keep[:, None], d, mixed)
+    elif kind == "gauss":
+        d, p, _ = synth.image_set(n_img, n, shared_frac=float(rng.uniform(0.1, 0.7)), seed=int(rng.integers(1 << 30)), kind="gauss")
     desc = np.concatenate([d[i * n:i * n + c] for i, c in enumerate(counts)] + [np.zeros((0, 128), np.float32)])
     pts = np.concatenate([p[i * n:i * n + c] for i, c in enumerate(counts)] + [np.zeros((0, 2))])
     pl = rng.integers(0, n_img, (int(rng.integers(1, 25)), 2)).astype(np.int32)
     thr = float(rng.choice([0.95, 0.9, 0.6]))
     gate = float(rng.choice([1e8, 120.0 ** 2]))
-    as_bytes = bool(rng.integers(2))
+    as_bytes = bool(rng.integers(2)) and kind != "gauss"
+    ctx.set_option("match_six_bit", int(rng.choice([1, 1, 0])))  # (0: no 6-bit table, the int8 pass comes first)
     ctx.set_option("pairs_per_launch", int(rng.choice([1, 3, 2048])))
     ctx.set_option("match_list_observe", int(rng.choice([0, 1, 2, 2])))  # (2: calls of nine chunks and more size their lists as they go)
     try:
@@ -81,6 +90,7 @@ def test_random_batch(ctx, oracle, seed):
     finally:
         ctx.set_option("pairs_per_launch", 2048)
         ctx.set_option("match_list_observe", 1)
+        ctx.set_option("match_six_bit", 1)
     starts = np.concatenate([[0], np.cumsum(counts)])
     assert off[0] == 0 and off[-1] == len(pairs)
     for k, (a, b) in enumerate(pl):

@@ -577,6 +577,84 @@ def test_flood_probe_changes_nothing(ctx, oracle):
             assert np.array_equal(got, exp) and np.array_equal(g1, e1) and np.array_equal(g2, e2), (thr, probe)
 
 
+def _mixed_set(rng, n, n_img, weight):
+    """Images of SIFT-like descriptors that share a common part: the cosine between unrelated descriptors grows as
+    the weight of the individual part shrinks (0.42: about 0.93, 0.6: about 0.88); the first 30 % of every image
+    re-detects image 0's features."""
+    base = synth.sift_like(rng, 1)[0]
+    d = np.clip(base[None, :] * 0.9 + synth.sift_like(rng, n_img * n) * weight, 0, 255).astype(np.float32)
+    shared = int(0.3 * n)
+    for im in range(1, n_img):
+        d[im * n:im * n + shared] = d[:shared]
+    return d, rng.uniform(0, 4000, (n_img * n, 2))
+
+
+@pytest.mark.parametrize("weight", [None, 0.6, 0.42])
+def test_six_bit_first_pass_changes_nothing(ctx, oracle, weight):
+    """The first bound pass of a batch call runs on 6-bit floats (e2m3) with a margin of about 0.1; the pairs it
+    floods are redone under the int8 bound (margin 0.02-0.04), those under the fp16 bound, and so on.  Lists with
+    the 6-bit pass equal the lists without it and the restatement's: on the usual descriptors (nothing floods), on
+    descriptors whose unrelated cosines (0.88) are inside the 6-bit margin of the threshold only, and on ones inside
+    the int8 margin too (0.93) -- in one chunk and in chunks of three pairs, where the later chunks learn from the
+    first whether to start with the 6-bit pass at all."""
+    rng = np.random.default_rng(5)
+    n, n_img = 1100, 5
+    if weight is None:
+        d, p, _ = synth.image_set(n_img, n, shared_frac=0.4, seed=31)
+    else:
+        d, p = _mixed_set(rng, n, n_img, weight)
+    counts = np.full(n_img, n, np.int32)
+    pl = synth.exhaustive_pairs(n_img)
+    s = ctx.imageset(counts, d, p)
+    lists = {}
+    try:
+        for six in (1, 0):
+            for per in (2048, 3):
+                ctx.set_option("match_six_bit", six)
+                ctx.set_option("pairs_per_launch", per)
+                res = s.match(pl, threshold=0.95, max_dist_sq=1e8)
+                lists[six, per] = (res.offsets(), res.pairs(), res.stats_ex())
+                res.close()
+    finally:
+        ctx.set_option("match_six_bit", 1)
+        ctx.set_option("pairs_per_launch", 2048)
+        s.close()
+    off, pairs, _ = lists[1, 2048]
+    for key, (o, q, _) in lists.items():
+        assert np.array_equal(o, off) and np.array_equal(q, pairs), key
+    for k in (0, 4, 9):
+        a, b = pl[k]
+        exp, _, _ = oracle.match(d[a * n:(a + 1) * n], p[a * n:(a + 1) * n], d[b * n:(b + 1) * n], p[b * n:(b + 1) * n],
+                                 threshold=0.95, max_dist_sq=1e8)
+        assert np.array_equal(pairs[off[k]:off[k + 1]], exp), k
+    # what the passes after the first had to do: nothing on the usual descriptors, the fp16 bound (or more) at 0.93
+    _, cells, filtered, redone = lists[1, 2048][2]
+    if weight is None:
+        assert cells == 0 and filtered == 0 and redone == 0
+    if weight == 0.42:
+        assert redone + filtered + cells > 0
+
+
+def test_six_bit_table_is_optional(ctx, oracle):
+    """An image set made while match_six_bit is 0 has no 6-bit table: its calls start with the int8 pass whatever the
+    option says later, and give the same lists as a set that has one."""
+    d, p, c = synth.image_set(3, 900, shared_frac=0.5, seed=8)
+    pl = synth.exhaustive_pairs(3)
+    with_table = ctx.imageset(c, d, p)
+    ctx.set_option("match_six_bit", 0)
+    try:
+        without = ctx.imageset(c, d, p)
+    finally:
+        ctx.set_option("match_six_bit", 1)
+    assert without.device_bytes() < with_table.device_bytes()
+    a, b = with_table.match(pl, threshold=0.9, max_dist_sq=1e8), without.match(pl, threshold=0.9, max_dist_sq=1e8)
+    assert np.array_equal(a.offsets(), b.offsets()) and np.array_equal(a.pairs(), b.pairs())
+    exp, _, _ = oracle.match(d[:900], p[:900], d[900:1800], p[900:1800], threshold=0.9, max_dist_sq=1e8)
+    assert np.array_equal(a.pairs()[a.offsets()[0]:a.offsets()[1]], exp)
+    for x in (a, b, with_table, without):
+        x.close()
+
+
 def test_later_chunks_skip_an_int8_pass_that_floods(ctx, oracle):
     """A call of several chunks at the reference's default threshold (match.hpp:59): the observed first chunk floods
     its int8 lists, so the later chunks skip that pass and start from the flood probe -- including pairs that would
