@@ -640,6 +640,9 @@ __device__ __forceinline__ int opaque_zero()
 // Operand map of both: lane l holds A[row l & 15][k-group l >> 4] and B[k-group l >> 4][col l & 15]
 // (8 halves or 16 bytes per group); result register q of lane l is C[4 (l >> 4) + q][l & 15].
 #define SIM_WAVES 4
+#ifndef SIX_BN
+#define SIX_BN 64 // columns per step of the e2m3 instance
+#endif
 #ifndef SIX_OCC
 #define SIX_OCC 5 // blocks per CU the e2m3 instance is compiled for
 #endif
@@ -920,17 +923,18 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
     constexpr bool F6 = FORM == 3;
     constexpr bool WIDE = FORM == 0 || FORM == 2; // 256-byte rows: the fp16 table's layout in memory and in LDS
     constexpr int ROWB = WIDE ? 256 : 128;                   // bytes per descriptor row in the table and in LDS
-    constexpr int DMA = SIM_BN * ROWB / 1024 / SIM_WAVES;  // LDS-DMA instructions per wave per step
-    static_assert(SIM_BN * ROWB % (1024 * SIM_WAVES) == 0 && SIM_BN == 64, "step must split evenly");
+    constexpr int BN = F6 ? SIX_BN : SIM_BN;              // columns per step
+    constexpr int DMA = BN * ROWB / 1024 / SIM_WAVES;  // LDS-DMA instructions per wave per step
+    static_assert(BN * ROWB % (1024 * SIM_WAVES) == 0 && (BN == 64 || (F6 && BN % 32 == 0)), "step must split evenly");
     static_assert(!(I8 || F6) || (!GENERAL && !DOT), "the int8 and e2m3 bounds have a strict cosine instance only");
     static_assert(GENERAL || !DOT, "the dot metric needs the general instance");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][SIM_BN * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BN * ROWB];
     // general instance: positions of the block's rows, of the staged columns, and the row bounds
     __shared__ double2 ptsRow[GENERAL ? SIM_BLOCK_ROWS : 1];
-    __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? SIM_BN : 1];
+    __shared__ double2 ptsCol[GENERAL ? 2 : 1][GENERAL ? BN : 1];
     __shared__ unsigned rowBound[GENERAL ? SIM_BLOCK_ROWS : 1];
-    __shared__ float colBar[MODE == 2 ? 2 : 1][MODE == 2 ? SIM_BN : 1]; // minus the bars of the staged columns
-    __shared__ unsigned colMaxL[MODE == 1 ? 2 : 1][MODE == 1 ? SIM_BN : 1]; // largest approximation of each staged column over the block's rows
+    __shared__ float colBar[MODE == 2 ? 2 : 1][MODE == 2 ? BN : 1]; // minus the bars of the staged columns
+    __shared__ unsigned colMaxL[MODE == 1 ? 2 : 1][MODE == 1 ? BN : 1]; // largest approximation of each staged column over the block's rows
 
     const int2 w = g.work[workItem];
     if (w.x < 0) return;
@@ -972,8 +976,8 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         for (int s = 0; s < NKB; s++)
             a[t][s] = *reinterpret_cast<const Frag *>(Arows + (size_t)(t * 16 + (lane & 15)) * ROWB + (s * 4 + (lane >> 4)) * 16);
 
-    // this block's steps of SIM_BN columns: [chunk0, nChunks)
-    const int allChunks = (pr.nB + SIM_BN - 1) / SIM_BN;
+    // this block's steps of BN columns: [chunk0, nChunks)
+    const int allChunks = (pr.nB + BN - 1) / BN;
     const int perPart = (allChunks + colParts - 1) / colParts;
     const int chunk0 = colPart * perPart;
     const int nChunks = min(allChunks, chunk0 + perPart);
@@ -993,19 +997,19 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         srcOff[u] = !WIDE ? (2 * line + (logical >> 3)) * 128 + ((logical & 7) << 4) : line * 256 + (logical << 4);
     }
     auto dma_issue = [&](int c, int buf) __attribute__((always_inline)) {
-        const unsigned char *src = Brows + (size_t)c * SIM_BN * ROWB;
+        const unsigned char *src = Brows + (size_t)c * BN * ROWB;
 #pragma unroll
         for (int u = 0; u < DMA; u++)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + srcOff[u]), (lptr_t)&lds[buf][(wave * DMA + u) * 1024], 16, 0, 0);
         if constexpr (GENERAL) { // the step's 64 pixel positions: one instruction (the table has no padding)
             if (wave == 0) {
-                const int j = min(c * SIM_BN + lane, pr.nB - 1);
+                const int j = min(c * BN + lane, pr.nB - 1);
                 __builtin_amdgcn_global_load_lds((gptr_t)(g.pts + pr.rowB32 + j), (lptr_t)&ptsCol[buf][0], 16, 0, 0);
             }
         }
         if constexpr (MODE == 2) { // the step's 64 column bars (minus the bar, as the first sweeps left them): one instruction
             if (wave == 0) {
-                const int j = min(c * SIM_BN + lane, pr.nB - 1);
+                const int j = min(c * BN + lane, pr.nB - 1);
                 __builtin_amdgcn_global_load_lds((gptr_t)(g.rowMax + pr.bestCol + j), (lptr_t)&colBar[buf][0], 4, 0, 0);
             }
         }
@@ -1130,7 +1134,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
                 for (int t = 0; t < 4; t++)
 #pragma unroll
                     for (int q = 0; q < 4; q += 2) cm = fmaxf(fmaxf(cm, acc.a[ct][t][q]), acc.a[ct][t][q + 1]);
-                atomicMax(&colMaxL[buf][(colBase & (SIM_BN - 1)) + ct * 16 + (lane & 15)], __float_as_uint(cm));
+                atomicMax(&colMaxL[buf][(colBase & (BN - 1)) + ct * 16 + (lane & 15)], __float_as_uint(cm));
             }
         } else {
             typename AccT::VT m[4] = {};
@@ -1138,7 +1142,7 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             sim_epilogue<AccT, DOT, GENERAL, MODE == 2>(g, pr, acc, rowBase, colBase, lane,
                                              typename AccT::VT(I8 ? thr_i : (F6 ? thr6 : (MODE == 2 ? 0.0f : thr_m))), wq, localLo,
                                              GeneralLds{ptsRow + (GENERAL ? wave * SIM_WAVE_ROWS : 0),
-                                                        &ptsCol[GENERAL ? buf : 0][GENERAL ? (colBase % SIM_BN) : 0],
+                                                        &ptsCol[GENERAL ? buf : 0][GENERAL ? (colBase % BN) : 0],
                                                         rowBound + (GENERAL ? wave * SIM_WAVE_ROWS : 0)}, m);
         }
     };
@@ -1163,10 +1167,11 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
         }
         // a strict wave whose slice has overflowed only keeps the staging going: the pair is redone anyway
         if (GENERAL || wq.n <= wq.cap) {
-            mfma_step(acc, buf, 0);
-            test(acc, c * SIM_BN, buf);
-            mfma_step(acc, buf, 1);
-            test(acc, c * SIM_BN + 32, buf);
+#pragma unroll
+            for (int sub = 0; sub < BN / 32; sub++) {
+                mfma_step(acc, buf, sub);
+                test(acc, c * BN + 32 * sub, buf);
+            }
         }
         if (!(ABL & 1)) __syncthreads(); // next step has landed (vmcnt) and nobody still reads this one
         if constexpr (MODE == 1) {
@@ -1175,13 +1180,13 @@ __device__ __forceinline__ void sim_block(const MatchArgs &g, const int workItem
             if (wave == (c & 3)) {
                 const unsigned v = colMaxL[buf][lane];
                 colMaxL[buf][lane] = 0u;
-                const int j = c * SIM_BN + lane;
+                const int j = c * BN + lane;
                 if (v != 0u && j < pr.nB) atomicMax(reinterpret_cast<unsigned *>(g.rowMax) + pr.bestCol + j, v);
             }
         }
     };
     if constexpr (MODE == 1) {
-        if (tid < 2 * SIM_BN) colMaxL[tid / SIM_BN][tid % SIM_BN] = 0u;
+        if (tid < 2 * BN) colMaxL[tid / BN][tid % BN] = 0u;
     }
     if (chunk0 < nChunks) dma_issue(chunk0, 0);
     __syncthreads();
@@ -1343,6 +1348,7 @@ static const SimVariant kSimVariants[] = {
     {match_sim_kernel<5, 3, false, false, 2>, nullptr, "e2m3, no candidate test (timing only)"},                // 8
     {match_sim_kernel<5, 3, false, false, 3>, nullptr, "e2m3, neither staging nor test (timing only)"},         // 9
     {match_sim_kernel<5, 3, false, false, 8>, nullptr, "e2m3, hits not queued (timing only)"},                  // 10
+    {match_sim_kernel<5, 3, false, false, 1>, nullptr, "e2m3, no staging (timing only)"},                       // 11
 };
 // cosine with the row-best filter (loose thresholds), and the dot metric: fp16 bound, two blocks per CU
 // Binary descriptors as 256 signs (+1 / -1) per row: the int32 sum is 256 - 2 * Hamming distance, exactly.
