@@ -1574,20 +1574,22 @@ __global__ __launch_bounds__(256) void ratio_apply_kernel(const MatchArgs g)
 }
 
 // Pairs whose candidate list overflowed (one block): ovfList[0] = count, then the pair indices.
-__global__ __launch_bounds__(256) void match_overflow_list_kernel(const MatchArgs g, int nPairs)
+__global__ __launch_bounds__(256) void match_overflow_list_kernel(const MatchArgs g, int nPairs, int sixRan)
 {
     __shared__ int n;
     if (threadIdx.x == 0) n = 0;
     __syncthreads();
-    int general = 0, redone = 0;
+    int general = 0, redone = 0, flagged = 0;
     for (int p = threadIdx.x; p < nPairs; p += blockDim.x) {
         const int f = g.pairOvf[p];
         if (f == 2) g.ovfList[1 + atomicAdd(&n, 1)] = p;
         general += (f == 1 || f == 2);
         redone += (f == 3);
+        flagged += (f != 0);
     }
     if (general) atomicAdd(&g.stats[2], (u64)general);
     if (redone) atomicAdd(&g.stats[3], (u64)redone);
+    if (flagged && sixRan) atomicAdd(&g.stats[4], (u64)flagged); // (every flag is then the e2m3 pass's or a later one's on a pair it flagged)
     __syncthreads();
     if (threadIdx.x == 0) {
         g.ovfList[0] = n;
@@ -1954,15 +1956,27 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     // next call on the result object starts from four times the size.
     const MatchKey key = {set, metric, threshold, maxDistSq, ratio, candCapMax, ctx->sim_variant};
     bool probing = false;
+    // how the last call fared whose counters have arrived (they are fetched at the end of every call, and nobody
+    // waits for them)
+    const bool sameKey = memcmp(&res->observedFor, &key, sizeof key) == 0;
+    bool haveStats = false;
+    u64 last[STATS_WORDS] = {};
+    if (res->statsEv && res->statsPending && hipEventQuery(res->statsEv) == hipSuccess) {
+        memcpy(last, res->hostStats.p, sizeof last);
+        res->statsPending = false;
+        haveStats = sameKey;
+    }
+    // A call whose e2m3 pass flooded half its pairs or more (descriptors whose unrelated cosines lie within that
+    // bound's margin of the threshold): the next fifteen calls with the same options start with the int8 pass, the
+    // sixteenth looks again.  (A call of several chunks learns the same from its first chunk.)
+    if (!sameKey) res->sixSkip = 0;
+    else if (haveStats && res->sixPairs > 0 && 2 * last[4] >= (u64)res->sixPairs) res->sixSkip = 15;
+    else if (res->sixSkip > 0) res->sixSkip--;
+    int64_t sixPairs = 0; // pairs of this call that took the e2m3 pass
     if (ctx->cand_observe && candCapMax > 0 && n_pairs > chunkPairs) {
-        if (res->candObserved > 0 && memcmp(&res->observedFor, &key, sizeof key) == 0) {
-            // how the last call fared whose counters have arrived (they are fetched at the end of every call,
-            // and nobody waits for them)
-            if (res->statsEv && res->statsPending && hipEventQuery(res->statsEv) == hipSuccess) {
-                const u64 *st4 = res->hostStats.as<u64>();
-                if (st4[1] + st4[2] + st4[3] > 0) res->candObserved = (int)std::min<int64_t>(candCapMax, (int64_t)res->candObserved * 4);
-                res->statsPending = false;
-            }
+        if (res->candObserved > 0 && sameKey) {
+            if (haveStats && last[1] + last[2] + last[3] > 0)
+                res->candObserved = (int)std::min<int64_t>(candCapMax, (int64_t)res->candObserved * 4);
         } else {
             res->candObserved = 0;
             res->floodObserved = false;
@@ -2167,7 +2181,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     SFM_HIP(ctx, res->ovfList.reserve(ovfListSet * sets));
     const size_t countsSet = (size_t)round_up((int64_t)((size_t)chunkPairs * sizeof(int)), 256);
     SFM_HIP(ctx, res->counts.reserve(countsSet * sets));
-    SFM_HIP(ctx, res->stats.reserve(4 * sizeof(u64)));
+    SFM_HIP(ctx, res->stats.reserve(STATS_WORDS * sizeof(u64)));
     const size_t killSet = (size_t)round_up((int64_t)((size_t)(maxBest ? maxBest : 1) * sizeof(int)), 256);
     if (ratio > 0.0f) SFM_HIP(ctx, res->kill.reserve(killSet * sets));
     // two-phase filtered passes (cosine): one float per row of a chunk
@@ -2198,7 +2212,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         res->pairFlag = 0; // (until this call's flag has been read)
     }
     hipStream_t st = ctx->stream;
-    if (n_pairs == 0) SFM_HIP(ctx, clear_ranges(st, {{res->offsets.p, sizeof(int64_t)}, {res->stats.p, 4 * sizeof(u64)}}));
+    if (n_pairs == 0) SFM_HIP(ctx, clear_ranges(st, {{res->offsets.p, sizeof(int64_t)}, {res->stats.p, STATS_WORDS * sizeof(u64)}}));
     if (overlap) { // the other two streams start where the first one stands
         SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
@@ -2315,7 +2329,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                                            {candCountBuf, (size_t)np * maxQueues * sizeof(int)},
                                            {pairOvfBuf, (size_t)(chunkPairs + FLAG_VALUES) * sizeof(int)},
                                            {res->offsets.p, ci == 0 ? sizeof(int64_t) : 0},
-                                           {res->stats.p, ci == 0 ? 4 * sizeof(u64) : 0}}));
+                                           {res->stats.p, ci == 0 ? STATS_WORDS * sizeof(u64) : 0}}));
         }
         const int nblk = chunkWorkCount[0][ci];
         // Grid of the passes that walk the work list: as many blocks as the device holds of that kernel at once (its
@@ -2341,7 +2355,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             // The e2m3 bound comes first where there is a table for it: twice the int8 rate, a wider margin.  The
             // pairs it floods are redone under the int8 bound; when half the observed first chunk was, the later
             // chunks start with int8 as if there were no such table.  (Single-pair calls have none.)
-            const bool sixFirst = strictFirst && !skipInt8 && g.desc6 && ctx->match_six_bit && ctx->sim_variant == 1 && (probe || !res->sixFlooded);
+            const bool sixFirst = strictFirst && !skipInt8 && g.desc6 && ctx->match_six_bit && ctx->sim_variant == 1 && res->sixSkip == 0 && (probe || !res->sixFlooded);
             if (strictFirst) {
                 SFM_HIP(ctx, sfm_span_begin(ctx, 0, st));
                 g.onlyFlagged = 0;
@@ -2426,7 +2440,8 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                 else
                     hipLaunchKernelGGL(match_cand_kernel<false>, dim3((maxQueues + 3) / 4, np), dim3(256), 0, st, g);
             }
-            hipLaunchKernelGGL(match_overflow_list_kernel, dim3(1), dim3(256), 0, st, g, np);
+            hipLaunchKernelGGL(match_overflow_list_kernel, dim3(1), dim3(256), 0, st, g, np, sixFirst ? 1 : 0);
+            if (sixFirst) sixPairs += np;
             hipLaunchKernelGGL(match_exact_kernel, dim3(4 * ctx->n_cus), dim3(256), 0, st, g);
             if (ratio > 0.0f) { // second sweep: rows whose second best comes too close lose their best
                 SFM_HIP(ctx, hipMemsetAsync(killBuf, 0, (size_t)bestLen * sizeof(int), st));
@@ -2527,8 +2542,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     res->upValid = true;
     if (n_pairs > 0 && !want_m1m2) {
         if (!res->statsEv) SFM_HIP(ctx, hipEventCreateWithFlags(&res->statsEv, hipEventDisableTiming));
-        SFM_HIP(ctx, res->hostStats.reserve(4 * sizeof(u64)));
-        SFM_HIP(ctx, hipMemcpyAsync(res->hostStats.p, res->stats.p, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        SFM_HIP(ctx, res->hostStats.reserve(STATS_WORDS * sizeof(u64)));
+        SFM_HIP(ctx, hipMemcpyAsync(res->hostStats.p, res->stats.p, STATS_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        res->sixPairs = sixPairs;
         SFM_HIP(ctx, hipEventRecord(res->statsEv, ctx->stream));
         res->statsPending = true;
     }

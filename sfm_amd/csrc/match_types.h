@@ -18,6 +18,7 @@ struct PairRec {
 };
 
 #define FLAG_VALUES 5 // values a pair's overflow flag takes, 0 included
+#define STATS_WORDS 5 // counters of a batch call (MatchArgs::stats)
 
 struct ImageRec {
     int32_t n;
@@ -54,7 +55,7 @@ struct MatchArgs {
     int colSplit;         // strict passes: column parts per row block (0 or 1 = a block walks all columns); work item y = row block | part << 24
     u64 *best;            // row keys and column keys of the chunk
     int *ovfList;         // pairs of the chunk whose candidate list overflowed, [0] = how many
-    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell, [2] pairs that needed the filtered passes, [3] pairs settled by the fp16 strict pass after the int8 one flooded
+    u64 *stats;           // [0] candidates scored from lists, [1] pairs scored cell by cell, [2] pairs that needed the filtered passes, [3] pairs settled by the fp16 strict pass after the int8 one flooded, [4] pairs the e2m3 pass flagged
     int candCap;
     int blockRows;        // rows of image A per block of the similarity kernel instance in use
     int wavesPerBlock;
@@ -107,6 +108,8 @@ struct sfm_match_result {
     DevBuf rowMax;           // two-phase filtered passes: a float per row of a chunk (per buffer set)
     DevBuf candProbe;        // lists of the first chunk of a call that observes how far they fill
     int candObserved = 0;    // candidate slots per pair sized from such a first chunk (0 = none yet)
+    int sixSkip = 0;            // calls with the same options that still skip the e2m3 pass, because a call before flooded it
+    int64_t sixPairs = 0;       // pairs of the last call that took the e2m3 pass (its counter [4] says how many of them it flagged)
     bool sixFlooded = false;    // in that first chunk half the pairs or more flooded their e2m3 lists: later chunks start with int8
     bool floodObserved = false; // in that first chunk nine pairs in ten flooded their int8 lists and went on to the filtered passes
     MatchKey observedFor = {nullptr, 0, 0.0f, 0.0f, 0.0f, 0, 0};

@@ -843,3 +843,27 @@ def test_single_pair_calls_remember_where_the_last_one_ended(ctx, oracle):
         got = ctx.match_pair(d[:n], p[:n], d[n:], p[n:], threshold=0.5, max_dist_sq=1e8, return_best=True)
         assert np.array_equal(got[0], exp), (k, which)
         assert np.array_equal(got[1], m1) and np.array_equal(got[2], m2), (k, which)
+
+
+def test_calls_remember_that_the_six_bit_pass_floods(ctx, oracle):
+    """One-chunk calls on descriptors whose unrelated cosines (0.88) are inside the 6-bit margin of the threshold: the
+    first call tries the 6-bit pass, floods it and goes on under the int8 bound; the following calls with the same
+    options on the same result object start with the int8 pass.  Every call gives the same lists, which are the
+    restatement's."""
+    rng = np.random.default_rng(19)
+    n, n_img = 1100, 4
+    d, p = _mixed_set(rng, n, n_img, 0.6)
+    pl = synth.exhaustive_pairs(n_img)
+    s = ctx.imageset(np.full(n_img, n, np.int32), d, p)
+    res = s.match(pl, threshold=0.95, max_dist_sq=1e8)
+    off, pairs = res.offsets(), res.pairs()
+    for _ in range(3):
+        res = s.match(pl, threshold=0.95, max_dist_sq=1e8, result=res)
+        assert np.array_equal(res.offsets(), off) and np.array_equal(res.pairs(), pairs)
+    other = s.match(pl, threshold=0.9, max_dist_sq=1e8, result=res)  # other options: the 6-bit pass is tried again
+    exp9, _, _ = oracle.match(d[:n], p[:n], d[n:2 * n], p[n:2 * n], threshold=0.9, max_dist_sq=1e8)
+    assert np.array_equal(other.pairs()[other.offsets()[0]:other.offsets()[1]], exp9)
+    exp, _, _ = oracle.match(d[:n], p[:n], d[n:2 * n], p[n:2 * n], threshold=0.95, max_dist_sq=1e8)
+    assert np.array_equal(pairs[off[0]:off[1]], exp)
+    other.close()
+    s.close()
