@@ -402,7 +402,7 @@ def bench_regimes(ctx, args, imgset, pair_list, flops_per_pair):
     nothing but true matches (nor does the e2m3 bound that now comes first); these rows show what the same entry point costs when it does not:
     the fp16 bound on the same data, the reference's default threshold (match.hpp:59: 0.5, where most cells
     pass and the row-best / column-best filter decides), Gaussian float descriptors, and a distribution whose
-    unrelated descriptors sit at cosine 0.93, inside the int8 margin of a 0.95 threshold (every pair is redone
+    unrelated descriptors sit at cosine 0.93, inside the e2m3 and int8 margins of a 0.95 threshold (every pair is redone
     with the fp16 bound).  `frac` prices the strict bound kernel alone against its MFMA peak; `end_to_end_frac`
     prices the whole call (all passes) against the peak of the bound the row starts with."""
     from sfm_amd import capi, synth

@@ -71,8 +71,9 @@ const char *sfm_version(void);
  * scoring launch with few blocks cuts every pair's correspondences over several
  * blocks and adds the errors up in order in a second kernel, default; 0 = one
  * block per 256 rows always; results are identical), "sim_variant"
- * (instance of the similarity kernel: 1 = int8 bound, the default; 0 = fp16
- * bound; 2..5 = ablations that give wrong results and exist for timing only),
+ * (instance of the similarity kernel: 1 = the default, the int8 bound, preceded
+ * by the 6-bit bound where "match_six_bit" provides its table; 0 = fp16
+ * bound; 2..11 = ablations that give wrong results and exist for timing only),
  * "ransac_filter" (1 = skip evaluations the
  * epipolar-distance pre-test proves to be outliers, default; 0 = evaluate
  * everything; results are identical), "ransac_mfma" (1 = unsplit scoring
