@@ -867,3 +867,48 @@ def test_calls_remember_that_the_six_bit_pass_floods(ctx, oracle):
     assert np.array_equal(pairs[off[0]:off[1]], exp)
     other.close()
     s.close()
+
+
+def _aligned_rows(rng, n):
+    """Rows of 32 non-zero elements out of 128, the same multiset of values in every row (so all rows have one norm,
+    32.4, and the 6-bit table one scale, 1/32): scaled, every value lies 0.05-0.15 above a representable one where the
+    step is 0.5, and rounds down."""
+    levels = np.array([4.14, 4.64, 5.14, 5.64, 6.14, 6.64, 7.14], np.float32)
+    values = np.resize(levels, 32)
+    rows = np.zeros((n, 128), np.float32)
+    for i in range(n):
+        rows[i, rng.choice(128, 32, replace=False)] = rng.permutation(values)
+    return rows
+
+
+def test_six_bit_margin_holds_when_rounding_errors_line_up(ctx, oracle):
+    """Descriptors made so that every non-zero element rounds down in the 6-bit table: the copy of a descriptor is
+    short by 2-3 % along the descriptor itself, so the approximate cosine of two near-equal descriptors is short by
+    nearly the whole margin, while their true cosines straddle the threshold (image B's rows are image A's with up
+    to two elements moved and up to six pairs of values swapped).  The lists must still be the restatement's."""
+    rng = np.random.default_rng(23)
+    n = 1500
+    A = _aligned_rows(rng, n)
+    B = A.copy()
+    for i in range(n):
+        nz = np.flatnonzero(B[i])
+        for _ in range(int(rng.integers(0, 3))):  # an element moved to an empty place
+            src = rng.choice(np.flatnonzero(B[i]))
+            dst = rng.choice(np.flatnonzero(B[i] == 0))
+            B[i, dst], B[i, src] = B[i, src], 0.0
+        for _ in range(int(rng.integers(0, 7))):  # two values swapped
+            j, k = rng.choice(np.flatnonzero(B[i]), 2, replace=False)
+            B[i, j], B[i, k] = B[i, k], B[i, j]
+    B = B[rng.permutation(n)]
+    pA, pB = rng.uniform(0, 1000, (n, 2)), rng.uniform(0, 1000, (n, 2))
+    s = ctx.imageset(np.array([n, n], np.int32), np.concatenate([A, B]), np.concatenate([pA, pB]))
+    for thr in (0.95, 0.965, 0.98):
+        res = s.match(np.array([[0, 1], [1, 0]], np.int32), threshold=thr, max_dist_sq=1e8)
+        off, pairs = res.offsets(), res.pairs()
+        exp, _, _ = oracle.match(A, pA, B, pB, threshold=thr, max_dist_sq=1e8)
+        rev, _, _ = oracle.match(B, pB, A, pA, threshold=thr, max_dist_sq=1e8)
+        assert 50 < len(exp) < n - 50, (thr, len(exp))  # (the threshold cuts through the cosines)
+        assert np.array_equal(pairs[off[0]:off[1]], exp) and np.array_equal(pairs[off[1]:off[2]], rev), thr
+        assert res.stats_ex()[1:] == (0, 0, 0)  # (and no later pass was needed: the 6-bit lists held them)
+        res.close()
+    s.close()
