@@ -1362,7 +1362,7 @@ static void (*const kSimRowMax)(const MatchArgs) = match_sim_walk_kernel<3, fals
 static void (*const kSimBar)(const MatchArgs) = match_sim_walk_kernel<2, false, false, false, 0, 2>;
 static void (*const kSimDot)(const MatchArgs) = match_sim_kernel<2, false, true, true, 0>;
 static void (*const kSimSix)(const MatchArgs) = match_sim_kernel<SIX_OCC, 3, false, false, 0>;        // e2m3 bound, every pair
-static void (*const kSimEight)(const MatchArgs) = match_sim_walk_kernel<5, 1, false, false, 0>; // int8 bound, the pairs that one flooded
+static void (*const kSimEight)(const MatchArgs) = match_sim_walk_kernel<4, 1, false, false, 0>; // int8 bound, the pairs that one flooded
 static const int kNumSimVariants = (int)(sizeof(kSimVariants) / sizeof(kSimVariants[0]));
 
 // ---------------------------------------------------------------------------------------
@@ -2382,7 +2382,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             if (sixFirst) { // pairs flooded under the e2m3 margin: int8 bound
                 g.onlyFlagged = 4;
                 g.nWork = nblk;
-                hipLaunchKernelGGL(kSimEight, dim3(std::min(nblk, walk_grid(5))), dim3(SIM_WAVES * 64), 0, st, g);
+                hipLaunchKernelGGL(kSimEight, dim3(std::min(nblk, walk_grid(4))), dim3(SIM_WAVES * 64), 0, st, g);
             }
             if (strictFirst && variant.strict16) { // pairs flooded under the wide int8 margin: fp16 bound
                 if (ctx->match_flood_probe && metric == SFM_METRIC_COSINE && pairGuess != 1)
