@@ -44,8 +44,8 @@ struct sfm_ctx {
     // a chunk's first bound pass is done, ev[3..5] its buffer set is clear again, ev[7..9] its records are on
     // the device (all three by set), ev[6] fork / join.
     hipStream_t stream2 = nullptr, stream3 = nullptr;
-#define SFM_CTX_EVENTS 10
-    hipEvent_t ev[SFM_CTX_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#define SFM_CTX_EVENTS 16
+    hipEvent_t ev[SFM_CTX_EVENTS] = {};
     int span_accumulate = 0;         // 1: sfm_ctx_last_kernel_ms sums over all calls since it was last read
     int sim_variant = 1;             // index into the similarity kernel's instance table (1 = int8 bound)
     // timing of the dominant kernels (HIP events on `stream`)

@@ -640,6 +640,13 @@ __device__ __forceinline__ int opaque_zero()
 // Operand map of both: lane l holds A[row l & 15][k-group l >> 4] and B[k-group l >> 4][col l & 15]
 // (8 halves or 16 bytes per group); result register q of lane l is C[4 (l >> 4) + q][l & 15].
 #define SIM_WAVES 4
+#ifndef MATCH_SETS
+#define MATCH_SETS 3 // sets of per-chunk buffers a batch call takes in turn
+#endif
+#define EV_CLEAR MATCH_SETS          // events of the context: [0, MATCH_SETS) a chunk's bound passes are done, then its set is clear again,
+#define EV_JOIN (2 * MATCH_SETS)     // fork / join of the streams,
+#define EV_UP (2 * MATCH_SETS + 1)   // a chunk's records are on the device
+static_assert(3 * MATCH_SETS + 1 <= SFM_CTX_EVENTS, "events per context");
 #ifndef SIX_BN
 #define SIX_BN 64 // columns per step of the e2m3 instance
 #endif
@@ -1772,8 +1779,8 @@ static int imageset_build(sfm_ctx *ctx, int n_images, const int32_t *counts, con
                 row += counts[k];
             }
             if (twoStreams) {
-                SET_HIP(hipEventRecord(ctx->ev[6], ctx->stream3));
-                SET_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev[6], 0));
+                SET_HIP(hipEventRecord(ctx->ev[EV_JOIN], ctx->stream3));
+                SET_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev[EV_JOIN], 0));
             }
             if (parts_u8 && r32 > 0) {
                 const int64_t n = r32 * dim;
@@ -2156,7 +2163,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     // keeps up, waits.  Events: ev[0..2] a chunk's bound passes are done, ev[3..5] its set is clear again
     // (by set), ev[6] fork / join of the two streams.
     const bool overlap = ctx->match_overlap && nChunks > 1 && !want_m1m2;
-    const int sets = overlap ? std::min(3, nChunks) : 1;
+    const int sets = overlap ? std::min(MATCH_SETS, nChunks) : 1;
     const int maxQueues = std::max(1, std::max((maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS + (maxNB + BLOCK_ROWS - 1) / BLOCK_ROWS,
                                                (maxNA + BLOCK_ROWS - 1) / BLOCK_ROWS * colSplit)) * wavesPerBlock;
     // lists: the first chunk of a call that observes has a region of its own at the maximum; the sets of the
@@ -2214,9 +2221,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
     hipStream_t st = ctx->stream;
     if (n_pairs == 0) SFM_HIP(ctx, clear_ranges(st, {{res->offsets.p, sizeof(int64_t)}, {res->stats.p, STATS_WORDS * sizeof(u64)}}));
     if (overlap) { // the other two streams start where the first one stands
-        SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[6], 0));
-        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev[6], 0));
+        SFM_HIP(ctx, hipEventRecord(ctx->ev[EV_JOIN], ctx->stream));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev[EV_JOIN], 0));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev[EV_JOIN], 0));
     }
 
     MatchArgs g;
@@ -2286,7 +2293,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
                              nImg, set->dim, metric, threshold, ratio, maxDistSq, dotStrict ? 1 : 0,
                              set->desc6.p ? set->imageStats.as<int>() + 9 * (size_t)nImg : nullptr};
         hipLaunchKernelGGL(pair_bounds_kernel, dim3((np + 255) / 256), dim3(256), 0, up, res->pairRecs.as<PairRec>() + c0, np, b);
-        if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[7 + (int)(ci % (size_t)sets)], up));
+        if (overlap) SFM_HIP(ctx, hipEventRecord(ctx->ev[EV_UP + (int)(ci % (size_t)sets)], up));
         return SFM_OK;
     };
     if (nChunks > 0) {
@@ -2301,7 +2308,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         // this chunk's set of buffers; st = the stream of its bound passes
         const int par = (int)(ci % (size_t)sets);
         st = ctx->stream;
-        if (overlap) SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[7 + par], 0)); // its records are on the device
+        if (overlap) SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[EV_UP + par], 0)); // its records are on the device
         char *const bestBuf = res->best.as<char>() + par * bestSet;
         char *const candCountBuf = res->candCount.as<char>() + par * candCountSet;
         char *const pairOvfBuf = res->pairOvf.as<char>() + par * pairOvfSet;
@@ -2323,7 +2330,7 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
         g.orient = 0;
         int64_t bestLen = recs[c1 - 1].bestCol + recs[c1 - 1].nB;
         if (overlap && ci >= (size_t)sets) { // the chunk that had this set before has written its lists and cleared it
-            SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[3 + par], 0));
+            SFM_HIP(ctx, hipStreamWaitEvent(st, ctx->ev[EV_CLEAR + par], 0));
         } else { // (the first chunk also clears the first offset and the call's counters)
             SFM_HIP(ctx, clear_ranges(st, {{bestBuf, (size_t)bestLen * sizeof(u64)},
                                            {candCountBuf, (size_t)np * maxQueues * sizeof(int)},
@@ -2528,13 +2535,13 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             if (maxBest > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)maxBest * sizeof(u64), st));
             SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)chunkPairs * maxQueues * sizeof(int), st));
             SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + FLAG_VALUES) * sizeof(int), st));
-            SFM_HIP(ctx, hipEventRecord(ctx->ev[3 + par], st));
+            SFM_HIP(ctx, hipEventRecord(ctx->ev[EV_CLEAR + par], st));
         }
         SFM_HIP(ctx, hipGetLastError());
     }
     if (overlap) { // the caller's stream continues once both are done
-        SFM_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream2));
-        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[6], 0));
+        SFM_HIP(ctx, hipEventRecord(ctx->ev[EV_JOIN], ctx->stream2));
+        SFM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[EV_JOIN], 0));
     }
     // for the next call on this result object: when its staging buffers are free again, and how this call fared
     if (!res->upDone) SFM_HIP(ctx, hipEventCreateWithFlags(&res->upDone, hipEventDisableTiming));
