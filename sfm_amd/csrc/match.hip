@@ -2532,9 +2532,9 @@ static int match_batch_impl(sfm_ctx *ctx, const sfm_imageset *set, const int32_t
             SFM_HIP(ctx, hipEventRecord(res->listEv[ci % LIST_RING], st));
         }
         if (overlap && ci + sets < (size_t)nChunks) { // clear the set for the chunk that takes it next (sizes: upper bounds)
-            if (maxBest > 0) SFM_HIP(ctx, hipMemsetAsync(bestBuf, 0, (size_t)maxBest * sizeof(u64), st));
-            SFM_HIP(ctx, hipMemsetAsync(candCountBuf, 0, (size_t)chunkPairs * maxQueues * sizeof(int), st));
-            SFM_HIP(ctx, hipMemsetAsync(pairOvfBuf, 0, (size_t)(chunkPairs + FLAG_VALUES) * sizeof(int), st));
+            SFM_HIP(ctx, clear_ranges(st, {{bestBuf, (size_t)maxBest * sizeof(u64)},
+                                           {candCountBuf, (size_t)chunkPairs * maxQueues * sizeof(int)},
+                                           {pairOvfBuf, (size_t)(chunkPairs + FLAG_VALUES) * sizeof(int)}}));
             SFM_HIP(ctx, hipEventRecord(ctx->ev[EV_CLEAR + par], st));
         }
         SFM_HIP(ctx, hipGetLastError());
