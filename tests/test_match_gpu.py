@@ -912,3 +912,45 @@ def test_six_bit_margin_holds_when_rounding_errors_line_up(ctx, oracle):
         assert res.stats_ex()[1:] == (0, 0, 0)  # (and no later pass was needed: the 6-bit lists held them)
         res.close()
     s.close()
+
+
+def test_int8_margin_holds_when_rounding_errors_line_up(ctx, oracle):
+    """The same for the int8 table (the first pass where there is no 6-bit table): 31 of a row's 32 non-zero elements
+    are a whole number plus 0.49 once scaled (the 32nd is the largest, 127), so every one rounds down by 0.49 and the
+    int32 sum of two near-equal rows is short by 80-90 % of the bound's margin, which is made of exactly these
+    worst cases (half a unit per element against the other row's L1 norm).  Image B's rows are image A's with up to
+    two elements moved and up to six pairs of values swapped: true cosines on both sides of the thresholds."""
+    rng = np.random.default_rng(29)
+    n = 1500
+    values = np.concatenate([[127.0], np.resize(np.arange(24, 124, 3), 31) + 0.49]).astype(np.float32)
+    A = np.zeros((n, 128), np.float32)
+    for i in range(n):
+        A[i, rng.choice(128, 32, replace=False)] = rng.permutation(values)
+    B = A.copy()
+    for i in range(n):
+        for _ in range(int(rng.integers(0, 3))):
+            nz = np.flatnonzero(B[i])
+            src = rng.choice(nz[B[i, nz] < 127])
+            dst = rng.choice(np.flatnonzero(B[i] == 0))
+            B[i, dst], B[i, src] = B[i, src], 0.0
+        for _ in range(int(rng.integers(0, 7))):
+            nz = np.flatnonzero(B[i])
+            j, k = rng.choice(nz[B[i, nz] < 127], 2, replace=False)
+            B[i, j], B[i, k] = B[i, k], B[i, j]
+    B = B[rng.permutation(n)]
+    pA, pB = rng.uniform(0, 1000, (n, 2)), rng.uniform(0, 1000, (n, 2))
+    ctx.set_option("match_six_bit", 0)
+    try:
+        s = ctx.imageset(np.array([n, n], np.int32), np.concatenate([A, B]), np.concatenate([pA, pB]))
+        for thr in (0.95, 0.97):
+            res = s.match(np.array([[0, 1], [1, 0]], np.int32), threshold=thr, max_dist_sq=1e8)
+            off, pairs = res.offsets(), res.pairs()
+            exp, _, _ = oracle.match(A, pA, B, pB, threshold=thr, max_dist_sq=1e8)
+            rev, _, _ = oracle.match(B, pB, A, pA, threshold=thr, max_dist_sq=1e8)
+            assert 50 < len(exp) < n - 50, (thr, len(exp))
+            assert np.array_equal(pairs[off[0]:off[1]], exp) and np.array_equal(pairs[off[1]:off[2]], rev), thr
+            assert res.stats_ex()[1:] == (0, 0, 0)  # (the int8 lists held them: no later pass)
+            res.close()
+        s.close()
+    finally:
+        ctx.set_option("match_six_bit", 1)
